@@ -1,0 +1,99 @@
+/*
+ * tts_hip.h -- C ABI of the MI355X (gfx950) Tacotron2 + WaveGlow + mel-STFT inference engine.
+ *
+ * This is the drop-in boundary for the reference's runtime seam: `BaseModel(runtime=...)`
+ * (/root/reference/models/interfaces/base_model.py:139-209) hands `compiled_infer` calls
+ * (base_model.py:367-375) to a `Runtime` object (utils/keras/runtimes/runtime.py:19-41) registered in
+ * `_runtimes` (utils/keras/runtimes/__init__.py:39-45).  The Python class `text_to_speech_amd.runtime.HipRuntime`
+ * is that object; it binds the functions below with ctypes.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative TTS_HIP_E* code otherwise; `tts_hip_last_error` gives the text;
+ *   - all tensors are dense, row-major, float32 (tokens/lengths int32), channels-last like the reference ([B, T, C]);
+ *   - `mem` says where caller buffers live: TTS_HIP_MEM_HOST (pageable/pinned host memory) or TTS_HIP_MEM_DEVICE
+ *     (pointers into the engine's GPU, e.g. torch tensors' data_ptr()); the engine never keeps caller pointers;
+ *   - one HIP stream per handle; calls on one handle are serialised by the caller (the reference calls
+ *     `infer` sequentially from one thread, base_model.py:702); different handles are independent;
+ *   - no global state besides the handle.
+ */
+#ifndef TTS_HIP_H_
+#define TTS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tts_hip_engine tts_hip_engine;
+
+enum {
+    TTS_HIP_OK = 0,
+    TTS_HIP_EINVAL = -1,   /* bad argument / shape */
+    TTS_HIP_ENOTREADY = -2,/* weights missing or not finalized */
+    TTS_HIP_EHIP = -3,     /* HIP runtime error (text in last_error) */
+    TTS_HIP_EIO = -4,      /* weight file error */
+    TTS_HIP_ENOMEM = -5
+};
+
+enum { TTS_HIP_MEM_HOST = 0, TTS_HIP_MEM_DEVICE = 1 };
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------------
+ * Replaces Runtime.load_engine(path) / Runtime.__init__ (runtimes/runtime.py:22-29).                               */
+int tts_hip_create(int device, tts_hip_engine** out);
+int tts_hip_destroy(tts_hip_engine* e);
+const char* tts_hip_last_error(const tts_hip_engine* e);
+/* ABI version of this header (bumped on any signature change). */
+int tts_hip_abi_version(void);
+
+/* ---- weights ----------------------------------------------------------------------------------------------------
+ * Replaces BaseModel._restore_model -> CheckpointManager.load (base_model.py:760-783,
+ * custom_train_objects/checkpoint_manager.py:169-215).  Tensor names and Keras layouts: text_to_speech_amd/weights.py.
+ * `tts_hip_set_tensor` copies `data` (host float32) into the engine; `tts_hip_load_weights` reads a TTSW file and
+ * calls it per tensor.  `tts_hip_finalize` builds the derived device buffers (transposed / permuted kernels, folded
+ * batch-norm, inverted 1x1 matrices -- the analogue of WaveGlow.set_weights -> build_inverse,
+ * waveglow_arch.py:308-310) for every model whose tensors are complete.  `speaker_embedding_dim` is 0 or 256.        */
+int tts_hip_set_tensor(tts_hip_engine* e, const char* name, const float* data, const int64_t* dims, int ndim);
+int tts_hip_load_weights(tts_hip_engine* e, const char* ttsw_path);
+int tts_hip_finalize(tts_hip_engine* e);
+/* 1 if the model ("waveglow" | "tacotron2" | "mel_stft") is ready to run, else 0. */
+int tts_hip_has_model(const tts_hip_engine* e, const char* model);
+
+/* ---- WaveGlow.infer  (architectures/waveglow_arch.py:244-306; called at models/tts/waveglow.py:82,96,104,112,128)
+ * mel   [B, T, 80]
+ * z     NULL (=> zeros: the reference's deterministic=True) or [B, T*32, 8] noise, consumed in the reference's order
+ *       (channels 0..3 initial audio, 4..5 early output after flow 8, 6..7 after flow 4)
+ * audio [B, T*256] out                                                                                              */
+int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                           float* audio, int mem);
+
+/* ---- Tacotron2.infer  (architectures/tacotron2_arch.py:866-925; called at models/tts/tacotron2.py:162)
+ * tokens        int32 [B, Tin], 0 = pad
+ * speaker       NULL or [B, speaker_embedding_dim]
+ * max_len       decoder steps allocated (the caller resolves the reference's float `max_length`, :886-892)
+ * early_stop    1: stop when every row has fired its stop token (:625-627); 0: run max_len steps
+ * prenet_masks  NULL (=> deterministic prenet) or [B, max_len, 2, 256] multiplicative dropout masks
+ * win_len/win_offset  attention window (:630-638); win_len <= 0 disables it
+ * outputs (any may be NULL): mel [B, max_len, 80], decoder_output [B, max_len, 80], stop_tokens [B, max_len],
+ *                            attention [B, max_len, Tin], lengths int32 [B]; *steps_run = loop iterations executed    */
+int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                            int max_len, int early_stop, const float* prenet_masks, int win_len, int win_offset,
+                            float* mel, float* decoder_output, float* stop_tokens, float* attention,
+                            int32_t* lengths, int32_t* steps_run, int mem);
+
+/* ---- TacotronSTFT.mel_spectrogram  (utils/audio/stft.py:242-274,306-314)
+ * audio [B, N] (N >= 1024) -> mel [B, N/256 + 1, 80]                                                                */
+int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem);
+
+/* ---- measurement hooks (used by bench.py; no effect on results) -------------------------------------------------
+ * Average duration in microseconds of the dominant kernel's launches (HIP events on the engine's stream) since the
+ * last reset, and how many launches were timed.  kind: 0 = WaveGlow WN in-layer GEMM, 1 = WN res/skip GEMM,
+ * 2 = Tacotron2 decoder step.  Timing is off unless enabled (events perturb nothing but cost a few us each).        */
+int tts_hip_kernel_timing(tts_hip_engine* e, int enable);
+int tts_hip_kernel_time_us(tts_hip_engine* e, int kind, double* avg_us, int64_t* launches);
+int tts_hip_synchronize(tts_hip_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTS_HIP_H_ */

@@ -1,0 +1,165 @@
+// engine.h -- internal state behind the tts_hip C ABI (include/tts_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tts_hip.h"
+
+struct HostTensor {
+    std::vector<int64_t> dims;
+    std::vector<float> data;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : dims) n *= (size_t)d;
+        return n;
+    }
+};
+
+// Growable device buffer (workspace).  Never shrinks; reallocated only when a larger request arrives.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    float* f() const { return (float*)p; }
+};
+
+// ---------------------------------------------------------------- WaveGlow (fixed reference geometry)
+struct WgLayerDev {
+    float* in_Bt = nullptr;     // [1024 (tanh/sigmoid interleaved per 128-tile)][2176 = 3*512 taps + 640 cond]
+    float* in_bias = nullptr;   // [1024] in_conv bias + cond bias, same row order
+    float* rs_Bt = nullptr;     // [rs_n][512]
+    float* rs_bias = nullptr;   // [rs_n]
+    int rs_n = 0;
+};
+struct WgFlowDev {
+    int n_rem = 0, n_half = 0;
+    float* start_w = nullptr;   // [n_half][512]
+    float* start_b = nullptr;   // [512]
+    float* end_w = nullptr;     // [2*n_half][512]
+    float* end_b = nullptr;     // [2*n_half]
+    float* inv = nullptr;       // [n_rem][n_rem]  out = audio @ inv
+    WgLayerDev layer[8];
+};
+struct WaveGlowDev {
+    bool ready = false;
+    float* up_Bt = nullptr;     // [32][640][384]
+    float* up_bias = nullptr;   // [640]
+    WgFlowDev flow[12];
+    std::vector<void*> allocs;
+    DevBuf spect, x, acts, skip, audio, io_mel, io_z, io_out;
+};
+
+// ---------------------------------------------------------------- Tacotron2
+struct ConvBnDev {              // conv k5 with batch-norm folded in
+    float* Bt = nullptr;        // [cout][5 * cin_pad]
+    float* bias = nullptr;      // [cout]  folded bias at unmasked rows
+    float* altbias = nullptr;   // [cout]  BN(0) = value at masked rows
+    int cin = 0, cin_pad = 0, cout = 0;
+};
+struct LstmDev {                // weights packed gate-interleaved: row r = 4*u + gate
+    float* W = nullptr;         // [4u][kin_total]  (input kernel rows then recurrent rows, K contiguous)
+    float* b = nullptr;         // [4u]
+    int units = 0, kin = 0;
+};
+struct Tacotron2Dev {
+    bool ready = false;
+    int enc_dim = 512, spk_dim = 0;
+    float* embeddings = nullptr;        // [148][512]
+    ConvBnDev enc_conv[3];
+    float* bl_in_Bt[2] = {nullptr, nullptr};   // BiLSTM input kernels [1024][512]
+    float* bl_in_b[2] = {nullptr, nullptr};    // [1024]
+    float* bl_rec[2] = {nullptr, nullptr};     // recurrent kernels transposed [1024][256]
+    float* prenet_w0 = nullptr;         // [256][80]   (transposed: out-major)
+    float* prenet_w1 = nullptr;         // [256][256]
+    LstmDev att, dec;
+    float* query_w = nullptr;           // [128][1024]
+    float* memory_Bt = nullptr;         // [128][enc]
+    float* value_w = nullptr;           // [128]
+    float* loc_conv = nullptr;          // [32][31][2]
+    float* loc_dense = nullptr;         // [128][32]   (transposed)
+    float* proj_w = nullptr;            // [81][1024 + enc]  (80 mel rows + gate row)
+    float* proj_b = nullptr;            // [81]
+    ConvBnDev post_conv[5];
+    std::vector<void*> allocs;
+    DevBuf ws;                          // per-call workspace arena
+    DevBuf io;                          // staging for host callers
+};
+
+struct MelStftDev {
+    bool ready = false;
+    float* basis_Bt = nullptr;          // [1056 (= 2*513 padded to 33*32)][1024]
+    float* mel_Bt = nullptr;            // [80][544]
+    std::vector<void*> allocs;
+    DevBuf frames, mag, io_in, io_out;
+};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int kind;
+};
+
+struct tts_hip_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    std::map<std::string, HostTensor> host;
+    WaveGlowDev wg;
+    Tacotron2Dev taco;
+    MelStftDev stft;
+    // timing hooks
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<TimedLaunch> ev_pool;
+    double time_sum_us[4] = {0, 0, 0, 0};
+    int64_t time_cnt[4] = {0, 0, 0, 0};
+};
+
+int set_err(const tts_hip_engine* e, int code, const char* fmt, ...);
+
+#define HIPCHK(e, call)                                                                                         \
+    do {                                                                                                        \
+        hipError_t _err = (call);                                                                               \
+        if (_err != hipSuccess)                                                                                 \
+            return set_err((e), TTS_HIP_EHIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_err)); \
+    } while (0)
+
+// timing helpers (engine.hip)
+void timing_begin(tts_hip_engine* e, int kind);
+void timing_end(tts_hip_engine* e);
+void timing_collect(tts_hip_engine* e);
+
+// model entry points (device pointers only)
+int waveglow_finalize(tts_hip_engine* e);
+int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio);
+void waveglow_free(tts_hip_engine* e);
+
+int tacotron2_finalize(tts_hip_engine* e);
+void tacotron2_free(tts_hip_engine* e);
+
+int melstft_finalize(tts_hip_engine* e);
+int melstft_run(tts_hip_engine* e, const float* d_audio, int B, int N, float* d_mel);
+void melstft_free(tts_hip_engine* e);
+
+// shared helpers
+const HostTensor* find_tensor(const tts_hip_engine* e, const std::string& name);
+// uploads a host tensor to a fresh device allocation tracked in `allocs`
+int upload(tts_hip_engine* e, const float* src, size_t n, float** dst, std::vector<void*>& allocs);
+int dev_alloc(tts_hip_engine* e, size_t n_floats, float** dst, std::vector<void*>& allocs, bool zero);

@@ -1,0 +1,280 @@
+// engine.hip -- C ABI entry points: handle lifetime, weight intake, host/device staging, timing hooks.
+#include "engine.h"
+
+#include <cstdarg>
+#include <cstring>
+
+int set_err(const tts_hip_engine* e, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    return code;
+}
+
+const HostTensor* find_tensor(const tts_hip_engine* e, const std::string& name) {
+    auto it = e->host.find(name);
+    return it == e->host.end() ? nullptr : &it->second;
+}
+
+int dev_alloc(tts_hip_engine* e, size_t n_floats, float** dst, std::vector<void*>& allocs, bool zero) {
+    void* p = nullptr;
+    HIPCHK(e, hipMalloc(&p, n_floats * sizeof(float)));
+    allocs.push_back(p);
+    if (zero) HIPCHK(e, hipMemsetAsync(p, 0, n_floats * sizeof(float), e->stream));
+    *dst = (float*)p;
+    return TTS_HIP_OK;
+}
+
+int upload(tts_hip_engine* e, const float* src, size_t n, float** dst, std::vector<void*>& allocs) {
+    int rc = dev_alloc(e, n, dst, allocs, false);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return TTS_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------- timing hooks
+void timing_begin(tts_hip_engine* e, int kind) {
+    if (!e->timing) return;
+    TimedLaunch t;
+    if (!e->ev_pool.empty()) {
+        t = e->ev_pool.back();
+        e->ev_pool.pop_back();
+    } else {
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+    }
+    t.kind = kind;
+    (void)hipEventRecord(t.a, e->stream);
+    e->timed.push_back(t);
+}
+void timing_end(tts_hip_engine* e) {
+    if (!e->timing || e->timed.empty()) return;
+    (void)hipEventRecord(e->timed.back().b, e->stream);
+}
+void timing_collect(tts_hip_engine* e) {
+    if (e->timed.empty()) return;
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& t : e->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && t.kind >= 0 && t.kind < 4) {
+            e->time_sum_us[t.kind] += 1e3 * ms;
+            e->time_cnt[t.kind] += 1;
+        }
+        e->ev_pool.push_back(t);
+    }
+    e->timed.clear();
+}
+
+// ------------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int tts_hip_abi_version(void) { return 1; }
+
+int tts_hip_create(int device, tts_hip_engine** out) {
+    if (!out) return TTS_HIP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TTS_HIP_EHIP;
+    if (device < 0 || device >= n) return TTS_HIP_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return TTS_HIP_EHIP;
+    tts_hip_engine* e = new (std::nothrow) tts_hip_engine();
+    if (!e) return TTS_HIP_ENOMEM;
+    e->device = device;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete e;
+        return TTS_HIP_EHIP;
+    }
+    *out = e;
+    return TTS_HIP_OK;
+}
+
+int tts_hip_destroy(tts_hip_engine* e) {
+    if (!e) return TTS_HIP_EINVAL;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    timing_collect(e);
+    for (auto& t : e->ev_pool) {
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    waveglow_free(e);
+    tacotron2_free(e);
+    melstft_free(e);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+    return TTS_HIP_OK;
+}
+
+const char* tts_hip_last_error(const tts_hip_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int tts_hip_set_tensor(tts_hip_engine* e, const char* name, const float* data, const int64_t* dims, int ndim) {
+    if (!e || !name || !data || !dims || ndim <= 0 || ndim > 8) return set_err(e, TTS_HIP_EINVAL, "set_tensor: bad argument");
+    HostTensor t;
+    t.dims.assign(dims, dims + ndim);
+    for (auto d : t.dims)
+        if (d <= 0) return set_err(e, TTS_HIP_EINVAL, "set_tensor(%s): non-positive dim", name);
+    t.data.assign(data, data + t.numel());
+    e->host[name] = std::move(t);
+    return TTS_HIP_OK;
+}
+
+int tts_hip_load_weights(tts_hip_engine* e, const char* path) {
+    if (!e || !path) return TTS_HIP_EINVAL;
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_err(e, TTS_HIP_EIO, "cannot open %s", path);
+    auto fail = [&](const char* what) {
+        fclose(f);
+        return set_err(e, TTS_HIP_EIO, "%s: %s", path, what);
+    };
+    char magic[4];
+    uint32_t ver = 0, n = 0;
+    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "TTSW", 4) != 0) return fail("not a TTSW file");
+    if (fread(&ver, 4, 1, f) != 1 || fread(&n, 4, 1, f) != 1 || ver != 1) return fail("unsupported version");
+    struct Ent {
+        std::string name;
+        std::vector<int64_t> dims;
+        uint64_t off, nbytes;
+    };
+    std::vector<Ent> ents(n);
+    for (auto& en : ents) {
+        uint32_t ln = 0, nd = 0;
+        if (fread(&ln, 4, 1, f) != 1 || ln > 4096) return fail("bad name length");
+        en.name.resize(ln);
+        if (fread(&en.name[0], 1, ln, f) != ln) return fail("truncated header");
+        if (fread(&nd, 4, 1, f) != 1 || nd == 0 || nd > 8) return fail("bad ndim");
+        en.dims.resize(nd);
+        if (fread(en.dims.data(), 8, nd, f) != nd) return fail("truncated header");
+        if (fread(&en.off, 8, 1, f) != 1 || fread(&en.nbytes, 8, 1, f) != 1) return fail("truncated header");
+    }
+    for (auto& en : ents) {
+        HostTensor t;
+        t.dims = en.dims;
+        if (t.numel() * sizeof(float) != en.nbytes) return fail("size mismatch");
+        t.data.resize(t.numel());
+        if (fseek(f, (long)en.off, SEEK_SET) != 0 || fread(t.data.data(), 1, en.nbytes, f) != en.nbytes)
+            return fail("truncated payload");
+        e->host[en.name] = std::move(t);
+    }
+    fclose(f);
+    return TTS_HIP_OK;
+}
+
+int tts_hip_finalize(tts_hip_engine* e) {
+    if (!e) return TTS_HIP_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc;
+    bool has_wg = false, has_taco = false;
+    for (auto& kv : e->host) {
+        if (kv.first.rfind("waveglow/", 0) == 0) has_wg = true;
+        if (kv.first.rfind("tacotron2/", 0) == 0) has_taco = true;
+    }
+    if (has_wg) {
+        if ((rc = waveglow_finalize(e))) return rc;
+        // the packed device copies are all that is needed from here on: drop 1 GB of host staging
+        for (auto it = e->host.begin(); it != e->host.end();)
+            it = (it->first.rfind("waveglow/", 0) == 0) ? e->host.erase(it) : std::next(it);
+    }
+    if (has_taco) {
+        if ((rc = tacotron2_finalize(e))) return rc;
+    }
+    if (!e->stft.ready) {
+        if ((rc = melstft_finalize(e))) return rc;
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return TTS_HIP_OK;
+}
+
+int tts_hip_has_model(const tts_hip_engine* e, const char* model) {
+    if (!e || !model) return 0;
+    if (!strcmp(model, "waveglow")) return e->wg.ready;
+    if (!strcmp(model, "tacotron2")) return e->taco.ready;
+    if (!strcmp(model, "mel_stft")) return e->stft.ready;
+    return 0;
+}
+
+int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                           float* audio, int mem) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (!e->wg.ready) return set_err(e, TTS_HIP_ENOTREADY, "waveglow weights not finalized");
+    if (!mel || !audio || B <= 0 || T <= 0) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: bad argument");
+    if ((long long)B * T * 32 > (1ll << 30)) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: B*T too large");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t n_mel = (size_t)B * T * 80, n_z = (size_t)B * T * 32 * 8, n_out = (size_t)B * T * 256;
+    const float* d_mel = mel;
+    const float* d_z = z;
+    float* d_out = audio;
+    if (mem == TTS_HIP_MEM_HOST) {
+        HIPCHK(e, e->wg.io_mel.ensure(n_mel * 4));
+        HIPCHK(e, e->wg.io_out.ensure(n_out * 4));
+        HIPCHK(e, hipMemcpyAsync(e->wg.io_mel.p, mel, n_mel * 4, hipMemcpyHostToDevice, e->stream));
+        d_mel = e->wg.io_mel.f();
+        d_out = e->wg.io_out.f();
+        if (z) {
+            HIPCHK(e, e->wg.io_z.ensure(n_z * 4));
+            HIPCHK(e, hipMemcpyAsync(e->wg.io_z.p, z, n_z * 4, hipMemcpyHostToDevice, e->stream));
+            d_z = e->wg.io_z.f();
+        }
+    } else if (mem != TTS_HIP_MEM_DEVICE) {
+        return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: bad mem kind %d", mem);
+    }
+    int rc = waveglow_run(e, d_mel, B, T, d_z, sigma, d_out);
+    if (rc) return rc;
+    if (mem == TTS_HIP_MEM_HOST)
+        HIPCHK(e, hipMemcpyAsync(audio, d_out, n_out * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return TTS_HIP_OK;
+}
+
+int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (!e->stft.ready) return set_err(e, TTS_HIP_ENOTREADY, "mel_stft not finalized");
+    if (!audio || !mel || B <= 0 || N < 1024) return set_err(e, TTS_HIP_EINVAL, "mel_stft: bad argument (N >= 1024)");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t n_in = (size_t)B * N, n_out = (size_t)B * (N / 256 + 1) * 80;
+    const float* d_in = audio;
+    float* d_out = mel;
+    if (mem == TTS_HIP_MEM_HOST) {
+        HIPCHK(e, e->stft.io_in.ensure(n_in * 4));
+        HIPCHK(e, e->stft.io_out.ensure(n_out * 4));
+        HIPCHK(e, hipMemcpyAsync(e->stft.io_in.p, audio, n_in * 4, hipMemcpyHostToDevice, e->stream));
+        d_in = e->stft.io_in.f();
+        d_out = e->stft.io_out.f();
+    } else if (mem != TTS_HIP_MEM_DEVICE) {
+        return set_err(e, TTS_HIP_EINVAL, "mel_stft: bad mem kind %d", mem);
+    }
+    int rc = melstft_run(e, d_in, B, N, d_out);
+    if (rc) return rc;
+    if (mem == TTS_HIP_MEM_HOST) HIPCHK(e, hipMemcpyAsync(mel, d_out, n_out * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return TTS_HIP_OK;
+}
+
+int tts_hip_kernel_timing(tts_hip_engine* e, int enable) {
+    if (!e) return TTS_HIP_EINVAL;
+    timing_collect(e);
+    e->timing = enable != 0;
+    for (int i = 0; i < 4; ++i) {
+        e->time_sum_us[i] = 0;
+        e->time_cnt[i] = 0;
+    }
+    return TTS_HIP_OK;
+}
+
+int tts_hip_kernel_time_us(tts_hip_engine* e, int kind, double* avg_us, int64_t* launches) {
+    if (!e || kind < 0 || kind >= 4) return TTS_HIP_EINVAL;
+    timing_collect(e);
+    if (avg_us) *avg_us = e->time_cnt[kind] ? e->time_sum_us[kind] / (double)e->time_cnt[kind] : 0.0;
+    if (launches) *launches = e->time_cnt[kind];
+    return TTS_HIP_OK;
+}
+
+int tts_hip_synchronize(tts_hip_engine* e) {
+    if (!e) return TTS_HIP_EINVAL;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return TTS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,462 @@
+// waveglow.hip -- WaveGlow flow inversion on gfx950.
+//
+// Replaces /root/reference/architectures/waveglow_arch.py:244-306 (WaveGlow.infer), :105-141 (WaveglowBlock.call) and
+// architectures/layers/invertible_conv.py:41-51 (Invertible1x1Conv reverse).
+//
+// HBM layout (all float32, channels-last, M = B * L positions, L = T * 32 groups of 8 samples):
+//   spect [M][640]   upsampled + regrouped conditioning (channel = mel * 8 + g), written once per call
+//   x     [M][512]   WN residual stream, updated in place by the res/skip GEMM epilogue
+//   acts  [M][512]   gated activations tanh * sigmoid, produced by the in-layer GEMM epilogue
+//   skip  [M][512]   running sum of skip outputs
+//   audio [M][8]     current flow state in the first n_rem columns; after the last flow it IS the output [B][L*8]
+// Per flow: start (VALU) -> 8 x { in-layer implicit GEMM (K = 3 taps * 512 + 640 cond, N = 1024, gate epilogue),
+// res/skip GEMM (K = 512, N = 1024) } -> end 1x1 + affine inverse + inverse 1x1 conv (one wave per position).
+#include "engine.h"
+#include "gemm_f32.h"
+
+#include <cmath>
+
+using namespace ttsgemm;
+
+namespace {
+
+constexpr int C = 512;        // n_channels
+constexpr int NCOND = 640;    // n_mel * n_group
+constexpr int KIN = 3 * C + NCOND;
+constexpr int UPK = 4 * 96;   // upsampling K: 4 taps x (80 padded to 96)
+
+// dst[n][koff + k] = src[k * src_ld + perm(n)]  for k < K   (Keras [K][N] kernel slice -> Bt rows)
+// perm: 0 identity; 1 WN gate interleave (per 128-row tile: 64 tanh channels then their 64 sigmoid partners)
+__global__ void pack_bt_kernel(const float* __restrict__ src, int K, int src_ld, float* __restrict__ dst, int N,
+                               long long ldb, int koff, int perm) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx % K);
+    int sn = n;
+    if (perm == 1) {
+        const int tile = n >> 7, q = n & 127;
+        sn = q < 64 ? tile * 64 + q : C + tile * 64 + (q - 64);
+    }
+    dst[(long long)n * ldb + koff + k] = src[(long long)k * src_ld + sn];
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst,
+                                 int N, int perm) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int sn = n;
+    if (perm == 1) {
+        const int tile = n >> 7, q = n & 127;
+        sn = q < 64 ? tile * 64 + q : C + tile * 64 + (q - 64);
+    }
+    dst[n] = a[sn] + (b ? b[sn] : 0.f);
+}
+
+// Upsampling kernel [1024][80 out][80 in] -> Bt[rr][n = o*8 + g][q*96 + i] = W[(rr*8 + g) + 256 q][o][i]
+__global__ void pack_upsample_kernel(const float* __restrict__ w, float* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = 32ll * 640 * UPK;
+    if (idx >= total) return;
+    const int kk = (int)(idx % UPK);
+    const int n = (int)((idx / UPK) % 640);
+    const int rr = (int)(idx / ((long long)UPK * 640));
+    const int q = kk / 96, i = kk % 96;
+    const int o = n >> 3, gidx = n & 7;
+    float v = 0.f;
+    if (i < 80) v = w[((long long)(rr * 8 + gidx + 256 * q) * 80 + o) * 80 + i];
+    dst[idx] = v;
+}
+
+__global__ void expand_up_bias_kernel(const float* __restrict__ b, float* __restrict__ dst) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < 640) dst[n] = b[n >> 3];
+}
+
+// audio[m][0..3] = sigma * z[m][0..3]  (z null => zeros)
+__global__ void init_audio_kernel(const float* __restrict__ z, float sigma, float* __restrict__ audio, long long M) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (z) {
+        v = *reinterpret_cast<const f32x4*>(z + m * 8);
+        v *= sigma;
+    }
+    *reinterpret_cast<f32x4*>(audio + m * 8) = v;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(audio + m * 8 + 4) = zero;
+}
+
+// x[m][c] = sum_{j < h} audio[m][j] * w[j][c] + b[c]      (start 1x1 conv, waveglow_arch.py:108)
+__global__ void wn_start_kernel(const float* __restrict__ audio, const float* __restrict__ w,
+                                const float* __restrict__ b, float* __restrict__ x, long long M, int h) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of channels
+    if (idx >= M * (C / 4)) return;
+    const long long m = idx / (C / 4);
+    const int c = (int)(idx % (C / 4)) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(b + c);
+    // the reference accumulates the dot product first and adds the bias last (Conv1D = conv + bias)
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < h; ++j) {
+        const float a = audio[m * 8 + j];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j * C + c);
+        s += a * wv;
+    }
+    acc += s;
+    *reinterpret_cast<f32x4*>(x + m * C + c) = acc;
+}
+
+// One wave per position: end 1x1 (512 -> 2h), affine inverse, inverse 1x1 conv, optional early-z prepend.
+//   waveglow_arch.py:141 (end), :284-290, :292-304
+__global__ __launch_bounds__(256) void wn_end_kernel(const float* __restrict__ skip, const float* __restrict__ end_w,
+                                                     const float* __restrict__ end_b, const float* __restrict__ inv,
+                                                     float* __restrict__ audio_io, float* __restrict__ audio_out,
+                                                     const float* __restrict__ z, int zoff, int n_early, float sigma,
+                                                     long long M, int h, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n2 = 2 * h, cch = 2 * h;       // end-conv outputs; flow channels
+    // this lane's slice of the end kernel: channels lane*8 .. lane*8+7 of every output row
+    float we[8][8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (o < n2) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(end_w + o * C + lane * 8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(end_w + o * C + lane * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                we[o][j] = w0[j];
+                we[o][4 + j] = w1[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) we[o][j] = 0.f;
+        }
+    }
+    for (int r = 0; r < rows_per_wave; ++r) {
+        const long long m = wave * rows_per_wave + r;
+        if (m >= M) return;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(skip + m * C + lane * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(skip + m * C + lane * 8 + 4);
+        float out[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p = fmaf(v0[j], we[o][j], p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p = fmaf(v1[j], we[o][4 + j], p);
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) p += __shfl_xor(p, s, 64);
+            out[o] = p;
+        }
+        // every lane now holds the 2h end-conv outputs; lane 0 finishes the (tiny) affine + 1x1 step
+        if (lane == 0) {
+            float a[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = j < cch ? audio_io[m * 8 + j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < h) y[j] = a[j];
+                else if (j < cch) {
+                    const float bb = out[j - h] + end_b[j - h];
+                    const float ss = out[j] + end_b[j];
+                    y[j] = (a[j] - bb) / expf(ss);
+                } else y[j] = 0.f;
+            }
+            float res[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float t = 0.f;
+                if (c < cch) {
+                    for (int j = 0; j < cch; ++j) t = fmaf(y[j], inv[j * cch + c], t);
+                }
+                res[c] = t;
+            }
+            float* dst = audio_out + m * 8;
+            for (int j = 0; j < n_early; ++j) dst[j] = z ? sigma * z[m * 8 + zoff + j] : 0.f;
+            for (int c = 0; c < cch; ++c) dst[n_early + c] = res[c];
+        }
+    }
+}
+
+int pack_bt(tts_hip_engine* e, const float* d_src, int K, int src_ld, float* dst, int N, long long ldb, int koff,
+            int perm) {
+    const long long total = (long long)N * K;
+    hipLaunchKernelGGL(pack_bt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, d_src, K,
+                       src_ld, dst, N, ldb, koff, perm);
+    HIPCHK(e, hipGetLastError());
+    return TTS_HIP_OK;
+}
+
+}  // namespace
+
+void waveglow_free(tts_hip_engine* e) {
+    for (void* p : e->wg.allocs) (void)hipFree(p);
+    e->wg.allocs.clear();
+    e->wg.spect.release();
+    e->wg.x.release();
+    e->wg.acts.release();
+    e->wg.skip.release();
+    e->wg.audio.release();
+    e->wg.io_mel.release();
+    e->wg.io_z.release();
+    e->wg.io_out.release();
+    e->wg.ready = false;
+}
+
+int waveglow_finalize(tts_hip_engine* e) {
+    WaveGlowDev& wg = e->wg;
+    waveglow_free(e);
+    auto need = [&](const std::string& name, std::initializer_list<int64_t> dims, const HostTensor** out) -> int {
+        const HostTensor* t = find_tensor(e, name);
+        if (!t) return set_err(e, TTS_HIP_ENOTREADY, "missing tensor %s", name.c_str());
+        if (t->dims != std::vector<int64_t>(dims))
+            return set_err(e, TTS_HIP_EINVAL, "tensor %s has an unexpected shape", name.c_str());
+        *out = t;
+        return 0;
+    };
+    int rc;
+    // staging buffer for raw Keras-layout kernels (largest: upsample 1024*80*80 = 6.55 M floats)
+    DevBuf stage, stage2;
+    HIPCHK(e, stage.ensure((size_t)1024 * 80 * 80 * 4));
+    HIPCHK(e, stage2.ensure((size_t)1024 * 4 * 2));
+    auto put = [&](DevBuf& b, const HostTensor* t) -> int {
+        HIPCHK(e, hipMemcpyAsync(b.p, t->data.data(), t->numel() * 4, hipMemcpyHostToDevice, e->stream));
+        return 0;
+    };
+    auto done = [&]() {
+        stage.release();
+        stage2.release();
+    };
+#define WGCHK(x)          \
+    if ((rc = (x))) {     \
+        done();           \
+        waveglow_free(e); \
+        return rc;        \
+    }
+    const HostTensor *t, *t2;
+    // ---- upsampling
+    WGCHK(need("waveglow/upsample/kernel", {1024, 80, 80}, &t));
+    WGCHK(dev_alloc(e, (size_t)32 * 640 * UPK, &wg.up_Bt, wg.allocs, false));
+    WGCHK(put(stage, t));
+    {
+        const long long total = 32ll * 640 * UPK;
+        hipLaunchKernelGGL(pack_upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
+                           stage.f(), wg.up_Bt);
+    }
+    WGCHK(need("waveglow/upsample/bias", {80}, &t));
+    WGCHK(dev_alloc(e, 640, &wg.up_bias, wg.allocs, false));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    WGCHK(put(stage, t));
+    hipLaunchKernelGGL(expand_up_bias_kernel, dim3(3), dim3(256), 0, e->stream, stage.f(), wg.up_bias);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+
+    // ---- flows
+    int n_half = 4, n_rem = 8;
+    for (int k = 0; k < 12; ++k) {
+        if (k % 4 == 0 && k > 0) {
+            n_half -= 1;
+            n_rem -= 2;
+        }
+        WgFlowDev& fl = wg.flow[k];
+        fl.n_rem = n_rem;
+        fl.n_half = n_half;
+        const std::string p = "waveglow/block-" + std::to_string(k);
+        WGCHK(need(p + "/start_conv/kernel", {1, n_half, C}, &t));
+        WGCHK(upload(e, t->data.data(), t->numel(), &fl.start_w, wg.allocs));
+        WGCHK(need(p + "/start_conv/bias", {C}, &t));
+        WGCHK(upload(e, t->data.data(), t->numel(), &fl.start_b, wg.allocs));
+        for (int i = 0; i < 8; ++i) {
+            WgLayerDev& ly = fl.layer[i];
+            const std::string si = std::to_string(i);
+            WGCHK(dev_alloc(e, (size_t)2 * C * KIN, &ly.in_Bt, wg.allocs, false));
+            WGCHK(need(p + "/in_conv-" + si + "/kernel", {3, C, 2 * C}, &t));
+            WGCHK(put(stage, t));
+            WGCHK(pack_bt(e, stage.f(), 3 * C, 2 * C, ly.in_Bt, 2 * C, KIN, 0, 1));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            WGCHK(need(p + "/cond_layer-" + si + "/kernel", {1, NCOND, 2 * C}, &t));
+            WGCHK(put(stage, t));
+            WGCHK(pack_bt(e, stage.f(), NCOND, 2 * C, ly.in_Bt, 2 * C, KIN, 3 * C, 1));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            WGCHK(need(p + "/in_conv-" + si + "/bias", {2 * C}, &t));
+            WGCHK(need(p + "/cond_layer-" + si + "/bias", {2 * C}, &t2));
+            WGCHK(dev_alloc(e, 2 * C, &ly.in_bias, wg.allocs, false));
+            HIPCHK(e, hipMemcpyAsync(stage2.p, t->data.data(), 2 * C * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(e, hipMemcpyAsync(stage2.f() + 2 * C, t2->data.data(), 2 * C * 4, hipMemcpyHostToDevice, e->stream));
+            hipLaunchKernelGGL(pack_bias_kernel, dim3(4), dim3(256), 0, e->stream, stage2.f(), stage2.f() + 2 * C,
+                               ly.in_bias, 2 * C, 1);
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            ly.rs_n = i < 7 ? 2 * C : C;
+            WGCHK(need(p + "/res_skip_conv-" + si + "/kernel", {1, C, ly.rs_n}, &t));
+            WGCHK(dev_alloc(e, (size_t)ly.rs_n * C, &ly.rs_Bt, wg.allocs, false));
+            WGCHK(put(stage, t));
+            WGCHK(pack_bt(e, stage.f(), C, ly.rs_n, ly.rs_Bt, ly.rs_n, C, 0, 0));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            WGCHK(need(p + "/res_skip_conv-" + si + "/bias", {ly.rs_n}, &t));
+            WGCHK(upload(e, t->data.data(), t->numel(), &ly.rs_bias, wg.allocs));
+        }
+        WGCHK(need(p + "/end_conv/kernel", {1, C, 2 * n_half}, &t));
+        {
+            std::vector<float> tr((size_t)2 * n_half * C);
+            for (int c = 0; c < C; ++c)
+                for (int o = 0; o < 2 * n_half; ++o) tr[(size_t)o * C + c] = t->data[(size_t)c * 2 * n_half + o];
+            WGCHK(upload(e, tr.data(), tr.size(), &fl.end_w, wg.allocs));
+        }
+        WGCHK(need(p + "/end_conv/bias", {2 * n_half}, &t));
+        WGCHK(upload(e, t->data.data(), t->numel(), &fl.end_b, wg.allocs));
+        // Invertible1x1Conv.build_inverse (invertible_conv.py:41-47): W = kernel[0]^T, W_inverse = inv(W)^T, and the
+        // reverse conv (kernel layout [1][in][out]) computes out = audio @ W_inverse = audio @ inv(kernel[0]^T)^T.
+        WGCHK(need("waveglow/invertible_conv-" + std::to_string(k) + "/conv/kernel", {1, n_rem, n_rem}, &t));
+        {
+            const int n = n_rem;
+            std::vector<double> a((size_t)n * 2 * n, 0.0);      // [W | I], W[r][c] = kernel[c][r]
+            for (int r = 0; r < n; ++r) {
+                for (int c = 0; c < n; ++c) a[(size_t)r * 2 * n + c] = (double)t->data[(size_t)c * n + r];
+                a[(size_t)r * 2 * n + n + r] = 1.0;
+            }
+            for (int col = 0; col < n; ++col) {                  // Gauss-Jordan with partial pivoting
+                int piv = col;
+                for (int r = col + 1; r < n; ++r)
+                    if (std::fabs(a[(size_t)r * 2 * n + col]) > std::fabs(a[(size_t)piv * 2 * n + col])) piv = r;
+                if (std::fabs(a[(size_t)piv * 2 * n + col]) < 1e-12) {
+                    done();
+                    waveglow_free(e);
+                    return set_err(e, TTS_HIP_EINVAL, "invertible_conv-%d kernel is singular", k);
+                }
+                if (piv != col)
+                    for (int c = 0; c < 2 * n; ++c) std::swap(a[(size_t)piv * 2 * n + c], a[(size_t)col * 2 * n + c]);
+                const double d = a[(size_t)col * 2 * n + col];
+                for (int c = 0; c < 2 * n; ++c) a[(size_t)col * 2 * n + c] /= d;
+                for (int r = 0; r < n; ++r) {
+                    if (r == col) continue;
+                    const double f = a[(size_t)r * 2 * n + col];
+                    if (f != 0.0)
+                        for (int c = 0; c < 2 * n; ++c) a[(size_t)r * 2 * n + c] -= f * a[(size_t)col * 2 * n + c];
+                }
+            }
+            std::vector<float> minv((size_t)n * n);              // M[j][c] = inv(W)[c][j]
+            for (int j = 0; j < n; ++j)
+                for (int c = 0; c < n; ++c) minv[(size_t)j * n + c] = (float)a[(size_t)c * 2 * n + n + j];
+            WGCHK(upload(e, minv.data(), minv.size(), &fl.inv, wg.allocs));
+        }
+    }
+#undef WGCHK
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    done();
+    wg.ready = true;
+    return TTS_HIP_OK;
+}
+
+int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio) {
+    WaveGlowDev& wg = e->wg;
+    const int L = T * 32;
+    const long long M = (long long)B * L;
+    HIPCHK(e, wg.spect.ensure((size_t)M * NCOND * 4));
+    HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
+    HIPCHK(e, wg.acts.ensure((size_t)M * C * 4));
+    HIPCHK(e, wg.skip.ensure((size_t)M * C * 4));
+    HIPCHK(e, wg.audio.ensure((size_t)M * 8 * 4));
+    hipStream_t st = e->stream;
+
+    // ---- upsample + regroup: 32 phase GEMMs [B*T, 4*96] x [384, 640] -> spect rows t*32 + rr
+    {
+        GemmArgs g{};
+        g.M = B * T;
+        g.N = 640;
+        g.L = T;
+        g.nseg = 4;
+        for (int q = 0; q < 4; ++q) g.seg[q] = ASeg{d_mel, 80, -q, 80, 96};
+        g.strideAz = 0;
+        g.Bt = wg.up_Bt;
+        g.ldb = UPK;
+        g.strideBz = 640ll * UPK;
+        g.bias = wg.up_bias;
+        g.strideBiasZ = 0;
+        g.mode = EPI_LINEAR;
+        g.act = ACT_NONE;
+        g.split = 640;
+        g.out0 = wg.spect.f();
+        g.ld0 = 32ll * NCOND;
+        g.acc0 = 0;
+        g.out1 = nullptr;
+        g.strideOutZ = NCOND;
+        HIPCHK(e, gemm_big(g, 32, st));
+    }
+    const unsigned mb = (unsigned)((M + 255) / 256);
+    hipLaunchKernelGGL(init_audio_kernel, dim3(mb), dim3(256), 0, st, d_z, sigma, wg.audio.f(), M);
+    HIPCHK(e, hipGetLastError());
+
+    int zoff = 4;
+    for (int k = 11; k >= 0; --k) {
+        const WgFlowDev& fl = wg.flow[k];
+        const int h = fl.n_half;
+        {
+            const long long n4 = M * (C / 4);
+            hipLaunchKernelGGL(wn_start_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, wg.audio.f(),
+                               fl.start_w, fl.start_b, wg.x.f(), M, h);
+            HIPCHK(e, hipGetLastError());
+        }
+        for (int i = 0; i < 8; ++i) {
+            const WgLayerDev& ly = fl.layer[i];
+            const int d = 1 << i;
+            GemmArgs g{};
+            g.M = (int)M;
+            g.N = 2 * C;
+            g.L = L;
+            g.nseg = 4;
+            g.seg[0] = ASeg{wg.x.f(), C, -d, C, C};
+            g.seg[1] = ASeg{wg.x.f(), C, 0, C, C};
+            g.seg[2] = ASeg{wg.x.f(), C, d, C, C};
+            g.seg[3] = ASeg{wg.spect.f(), NCOND, 0, NCOND, NCOND};
+            g.Bt = ly.in_Bt;
+            g.ldb = KIN;
+            g.bias = ly.in_bias;
+            g.mode = EPI_GATE;
+            g.out0 = wg.acts.f();
+            g.ld0 = C;
+            g.split = 2 * C;
+            timing_begin(e, 0);
+            HIPCHK(e, gemm_big(g, 1, st));
+            timing_end(e);
+
+            GemmArgs r{};
+            r.M = (int)M;
+            r.N = ly.rs_n;
+            r.L = (int)M;
+            r.nseg = 1;
+            r.seg[0] = ASeg{wg.acts.f(), C, 0, C, C};
+            r.Bt = ly.rs_Bt;
+            r.ldb = C;
+            r.bias = ly.rs_bias;
+            r.mode = EPI_LINEAR;
+            r.act = ACT_NONE;
+            if (i < 7) {                 // res -> x (+=), skip -> skip (= for the first layer, += after)
+                r.split = C;
+                r.out0 = wg.x.f();
+                r.ld0 = C;
+                r.acc0 = 1;
+                r.out1 = wg.skip.f();
+                r.ld1 = C;
+                r.acc1 = i > 0;
+            } else {                     // last layer: 512 outputs, all skip
+                r.split = C;
+                r.out0 = wg.skip.f();
+                r.ld0 = C;
+                r.acc0 = 1;
+                r.out1 = nullptr;
+            }
+            timing_begin(e, 1);
+            HIPCHK(e, gemm_big(r, 1, st));
+            timing_end(e);
+        }
+        const bool early = (k % 4 == 0) && k > 0;
+        float* dst = (k == 0) ? d_audio : wg.audio.f();
+        const int rows_per_wave = 8;
+        const long long waves = (M + rows_per_wave - 1) / rows_per_wave;
+        hipLaunchKernelGGL(wn_end_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, wg.skip.f(), fl.end_w,
+                           fl.end_b, fl.inv, wg.audio.f(), dst, d_z, zoff, early ? 2 : 0, sigma, M, h, rows_per_wave);
+        HIPCHK(e, hipGetLastError());
+        if (early) zoff += 2;
+    }
+    return TTS_HIP_OK;
+}

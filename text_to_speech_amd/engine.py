@@ -1,0 +1,212 @@
+"""`HipEngine`: Python owner of one `tts_hip_engine` handle (one GPU, one HIP stream).
+
+Inputs may be numpy arrays (host buffers: the library stages them over PCIe) or torch CUDA tensors (device buffers:
+passed by pointer, results returned as torch tensors on the same device).  PyTorch is only used to host device memory.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import HipLibraryError, MEM_DEVICE, MEM_HOST
+
+# field order of the reference's namedtuple (architectures/tacotron2_arch.py:52-56)
+Tacotron2InferenceOutput = namedtuple(
+    'Tacotron2InferenceOutput', ['decoder_output', 'mel', 'stop_tokens', 'attention_weights', 'lengths'])
+
+KERNEL_WN_IN, KERNEL_WN_RES_SKIP, KERNEL_DECODER_STEP = 0, 1, 2
+
+
+def _is_torch_cuda(x) -> bool:
+    return hasattr(x, 'data_ptr') and hasattr(x, 'is_cuda') and bool(x.is_cuda)
+
+
+class HipEngine:
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load_library()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.tts_hip_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise HipLibraryError(f'tts_hip_create(device={device}) failed with code {rc} (no usable MI355X GPU?)')
+        self.device = int(device)
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.tts_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.tts_hip_last_error(self._h)
+            raise HipLibraryError(f'{what} failed ({rc}): {msg.decode("utf-8", "replace") if msg else ""}')
+
+    def _torch(self):
+        import torch
+        return torch
+
+    def _sync_torch(self):
+        torch = self._torch()
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # ------------------------------------------------------------------ weights
+    def set_tensor(self, name: str, array) -> None:
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        dims = (ctypes.c_int64 * a.ndim)(*a.shape)
+        self._check(self._lib.tts_hip_set_tensor(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), dims,
+                                                 a.ndim), f'set_tensor({name})')
+
+    def load_state(self, tensors) -> None:
+        for k, v in tensors.items():
+            self.set_tensor(k, v)
+
+    def load_weights(self, path: str) -> None:
+        self._check(self._lib.tts_hip_load_weights(self._h, str(path).encode()), f'load_weights({path})')
+
+    def finalize(self) -> None:
+        self._check(self._lib.tts_hip_finalize(self._h), 'finalize')
+
+    def has_model(self, model: str) -> bool:
+        return bool(self._lib.tts_hip_has_model(self._h, model.encode()))
+
+    # ------------------------------------------------------------------ WaveGlow
+    def waveglow_infer(self, mel, z=None, sigma: float = 1.0):
+        """mel [B, T, 80] (+ optional z [B, T*32, 8]) -> audio [B, T*256]."""
+        if _is_torch_cuda(mel):
+            torch = self._torch()
+            mel = mel.to(torch.float32).contiguous()
+            if mel.dim() != 3 or mel.shape[2] != 80:
+                raise ValueError(f'mel must be [B, T, 80], got {tuple(mel.shape)}')
+            B, T = int(mel.shape[0]), int(mel.shape[1])
+            zp = None
+            if z is not None:
+                z = z.to(device=mel.device, dtype=torch.float32).contiguous()
+                if tuple(z.shape) != (B, T * 32, 8):
+                    raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {tuple(z.shape)}')
+                zp = ctypes.c_void_p(z.data_ptr())
+            out = torch.empty((B, T * 256), dtype=torch.float32, device=mel.device)
+            self._sync_torch()
+            self._check(self._lib.tts_hip_waveglow_infer(self._h, ctypes.c_void_p(mel.data_ptr()), B, T, zp,
+                                                         float(sigma), ctypes.c_void_p(out.data_ptr()), MEM_DEVICE),
+                        'waveglow_infer')
+            return out
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        if mel.ndim != 3 or mel.shape[2] != 80:
+            raise ValueError(f'mel must be [B, T, 80], got {mel.shape}')
+        B, T = mel.shape[:2]
+        zp = None
+        if z is not None:
+            z = np.ascontiguousarray(z, dtype=np.float32)
+            if z.shape != (B, T * 32, 8):
+                raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {z.shape}')
+            zp = z.ctypes.data_as(ctypes.c_void_p)
+        out = np.empty((B, T * 256), dtype=np.float32)
+        self._check(self._lib.tts_hip_waveglow_infer(self._h, mel.ctypes.data_as(ctypes.c_void_p), B, T, zp,
+                                                     float(sigma), out.ctypes.data_as(ctypes.c_void_p), MEM_HOST),
+                    'waveglow_infer')
+        return out
+
+    # ------------------------------------------------------------------ Tacotron2
+    def tacotron2_infer(self, tokens, speaker=None, max_len: int = 1000, early_stopping: bool = True,
+                        prenet_masks=None, attn_mask_win_len=None, attn_mask_offset: int = 0, want_attention=True):
+        """tokens int32 [B, Tin] -> Tacotron2InferenceOutput of numpy arrays (or torch tensors for CUDA tokens)."""
+        dev = _is_torch_cuda(tokens)
+        if dev:
+            torch = self._torch()
+            tok = tokens.to(torch.int32).contiguous()
+            B, Tin = int(tok.shape[0]), int(tok.shape[1])
+            device = tok.device
+            mk = lambda shape, dt=None: torch.zeros(shape, dtype=dt or torch.float32, device=device)
+            ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+            if speaker is not None:
+                speaker = speaker.to(device=device, dtype=torch.float32).contiguous()
+            if prenet_masks is not None:
+                prenet_masks = prenet_masks.to(device=device, dtype=torch.float32).contiguous()
+            i32 = torch.int32
+        else:
+            tok = np.ascontiguousarray(tokens, dtype=np.int32)
+            if tok.ndim != 2:
+                raise ValueError(f'tokens must be [B, Tin], got {tok.shape}')
+            B, Tin = tok.shape
+            mk = lambda shape, dt=None: np.zeros(shape, dtype=dt or np.float32)
+            ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+            if speaker is not None:
+                speaker = np.ascontiguousarray(speaker, dtype=np.float32)
+            if prenet_masks is not None:
+                prenet_masks = np.ascontiguousarray(prenet_masks, dtype=np.float32)
+            i32 = np.int32
+        max_len = int(max_len)
+        if max_len <= 0:
+            raise ValueError('max_len must be positive')
+        if prenet_masks is not None and tuple(prenet_masks.shape) != (B, max_len, 2, 256):
+            raise ValueError(f'prenet_masks must be [B, max_len, 2, 256], got {tuple(prenet_masks.shape)}')
+        mel = mk((B, max_len, 80))
+        dec = mk((B, max_len, 80))
+        stop = mk((B, max_len))
+        attn = mk((B, max_len, Tin)) if want_attention else None
+        lengths = mk((B,), i32)
+        steps = ctypes.c_int32(0)
+        if dev:
+            self._sync_torch()
+        win = int(attn_mask_win_len) if attn_mask_win_len is not None else 0
+        self._check(self._lib.tts_hip_tacotron2_infer(
+            self._h, ptr(tok), B, Tin, ptr(speaker), max_len, 1 if early_stopping else 0, ptr(prenet_masks),
+            win, int(attn_mask_offset), ptr(mel), ptr(dec), ptr(stop), ptr(attn), ptr(lengths),
+            ctypes.cast(ctypes.byref(steps), ctypes.c_void_p), MEM_DEVICE if dev else MEM_HOST), 'tacotron2_infer')
+        out = Tacotron2InferenceOutput(decoder_output=dec, mel=mel, stop_tokens=stop, attention_weights=attn,
+                                       lengths=lengths)
+        self.last_steps = int(steps.value)
+        return out
+
+    # ------------------------------------------------------------------ mel-STFT
+    def mel_stft(self, audio):
+        """audio [N] or [B, N] -> mel [B, N // 256 + 1, 80] (the reference's TacotronSTFT()(audio))."""
+        if _is_torch_cuda(audio):
+            torch = self._torch()
+            a = audio.to(torch.float32)
+            if a.dim() == 1:
+                a = a[None]
+            if a.shape[1] < 1024:
+                a = torch.nn.functional.pad(a, (0, 1024 - a.shape[1]))
+            a = a.contiguous()
+            B, N = int(a.shape[0]), int(a.shape[1])
+            out = torch.empty((B, N // 256 + 1, 80), dtype=torch.float32, device=a.device)
+            self._sync_torch()
+            self._check(self._lib.tts_hip_mel_stft(self._h, ctypes.c_void_p(a.data_ptr()), B, N,
+                                                   ctypes.c_void_p(out.data_ptr()), MEM_DEVICE), 'mel_stft')
+            return out
+        a = np.asarray(audio, dtype=np.float32)
+        if a.ndim == 1:
+            a = a[None]
+        if a.shape[1] < 1024:                     # MelSTFT.__call__ pads short audio (utils/audio/stft.py:113-115)
+            a = np.pad(a, [(0, 0), (0, 1024 - a.shape[1])])
+        a = np.ascontiguousarray(a)
+        B, N = a.shape
+        out = np.empty((B, N // 256 + 1, 80), dtype=np.float32)
+        self._check(self._lib.tts_hip_mel_stft(self._h, a.ctypes.data_as(ctypes.c_void_p), B, N,
+                                               out.ctypes.data_as(ctypes.c_void_p), MEM_HOST), 'mel_stft')
+        return out
+
+    # ------------------------------------------------------------------ measurement hooks
+    def kernel_timing(self, enable: bool) -> None:
+        self._check(self._lib.tts_hip_kernel_timing(self._h, 1 if enable else 0), 'kernel_timing')
+
+    def kernel_time_us(self, kind: int):
+        avg = ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        self._check(self._lib.tts_hip_kernel_time_us(self._h, int(kind), ctypes.byref(avg), ctypes.byref(n)),
+                    'kernel_time_us')
+        return avg.value, n.value
+
+    def synchronize(self) -> None:
+        self._check(self._lib.tts_hip_synchronize(self._h), 'synchronize')
