@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: WaveGlow vocoding of precomputed 80x800 mels, batch 8, fp32, per MI355X (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path (tts_hip_waveglow_infer through the C ABI) over one batch of synthetic mels that is
+already resident in HBM.  With N > 1 every rank vocodes its own batch of 8 utterances (utterances are independent:
+no data-path collective, weak scaling); the timed region is bracketed by barrier + synchronize and the MAX over ranks
+is reported.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- dominant kernel = the WN in-layer implicit GEMM (K = 3*512 + 640, N = 1024).  `achieved` = algorithmic
+                  FLOPs per launch / average launch duration measured with HIP events on the engine's stream.
+  cpu_baseline -- the numpy oracle (a CPU port of the reference algorithm, NOT the reference's TF2 path, which cannot run
+                  here) timed on a bounded sample on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BATCH, FRAMES = 8, 800                 # BASELINE.json configs[1]
+SAMPLE_RATE = 22050
+
+
+def wn_in_layer_flops(M: int) -> float:
+    """Algorithmic FLOPs of one WN in-layer GEMM launch: dilated k3 conv 512->1024 + cond 1x1 640->1024 over M positions."""
+    return 2.0 * M * (3 * 512 + 640) * 1024
+
+
+def cpu_baseline(wg_weights, cfg, frames: int, threads: int):
+    """Times the numpy oracle on `frames` mel frames, batch 1 (oracle = checker; here only as the reported CPU leg)."""
+    from oracle import waveglow_ref
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                   # pragma: no cover
+        threadpool_limits = None
+    mel = np.random.default_rng(7).uniform(-11.5, 1.2, (1, frames, 80)).astype(np.float32)
+    z = np.random.default_rng(11).standard_normal((1, frames * 32, 8)).astype(np.float32)
+
+    def run():
+        t0 = time.perf_counter()
+        waveglow_ref.infer(mel, wg_weights, cfg, z=z)
+        return time.perf_counter() - t0
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=threads):
+            dt = run()
+    else:
+        dt = run()
+    return {
+        'value': frames * 256 / dt, 'unit': 'audio samples/s', 'cores': threads, 'kind': 'port',
+        'sample': f'numpy oracle (OpenBLAS, {threads} threads), WaveGlow batch 1 x {frames} frames, one run of '
+                  f'{dt:.1f} s; stand-in for the reference TF2 CPU path, which cannot be imported here',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=BATCH)
+    ap.add_argument('--frames', type=int, default=FRAMES)
+    ap.add_argument('--cpu-frames', type=int, default=480, help='mel frames of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N')
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import WaveGlowConfig
+    from text_to_speech_amd.engine import HipEngine, KERNEL_WN_IN
+
+    cfg = WaveGlowConfig()
+    w = weights.synth_waveglow(cfg, seed=1234)
+    eng = HipEngine(local_rank)
+    eng.load_state(w)
+    eng.finalize()
+
+    B, T = args.batch, args.frames
+    dev = torch.device('cuda', local_rank)
+    # per-rank shard of the job: B utterances (seeded per rank), resident in HBM before the timed region
+    mel = torch.from_numpy(np.random.default_rng(7 + rank).uniform(-11.5, 1.2, (B, T, 80)).astype(np.float32)).to(dev)
+    z = torch.from_numpy(np.random.default_rng(11 + rank).standard_normal((B, T * 32, 8)).astype(np.float32)).to(dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.waveglow_infer(mel, z=z, sigma=1.0)
+    if not args.no_kernel_timing:
+        eng.kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.waveglow_infer(mel, z=z, sigma=1.0)       # returns after the engine stream has drained
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert bool(torch.isfinite(out).all())
+
+    avg_us, launches = (0.0, 0) if args.no_kernel_timing else eng.kernel_time_us(KERNEL_WN_IN)
+    samples = world * B * T * 256 * args.steps
+    result = None
+    if rank == 0:
+        M = B * T * 32
+        roofline = None
+        if launches:
+            achieved = wn_in_layer_flops(M) / (avg_us * 1e-6) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                        'kernel': 'gemm_f32_kernel<4,1,2,4> (WN in-layer implicit GEMM)', 'launches_timed': launches,
+                        'avg_launch_us': avg_us}
+        cpu = None
+        if args.cpu_frames > 0:
+            threads = min(os.cpu_count() or 1, 16)
+            cpu = cpu_baseline(w, cfg, args.cpu_frames, threads)
+        result = {
+            'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)',
+            'value': samples / dt, 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'WaveGlow-only vocoding of precomputed 80x{T} mel, batch {B} per GPU, fp32 '
+                                   f'(BASELINE.json configs[1])', 'batch_per_gpu': B, 'mel_frames': T,
+                       'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
+                       'weights': 'seeded synthetic (rng 1234)'},
+            'x_realtime': samples / dt / SAMPLE_RATE,
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()
