@@ -23,8 +23,6 @@ namespace ttsgemm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
-constexpr int LDSK = BK + 4;       // padded row length in floats (144 B)
 constexpr int MAX_SEG = 5;
 
 struct ASeg {
@@ -69,14 +67,32 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 __device__ __forceinline__ float sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// WR x WC waves, each owning RT x CT MFMA tiles of 32x32.
-template <int WR, int WC, int RT, int CT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+// Raw buffer loads: out-of-range offsets (>= num_records = 2^31) return 0, which gives branch-free zero fill for
+// rows outside the sequence / matrix (cdna_hip_programming.md T8).  Descriptors are built from wave-uniform values.
+constexpr unsigned OOB = 0x80000000u;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+// WR x WC waves, each owning RT x CT MFMA tiles of 32x32.  TAG only separates instantiations by name so that
+// profiles list the WaveGlow in-layer GEMM, the res/skip GEMM and the generic uses as different kernels.
+// BK = K extent of one LDS stage (16 or 32); OCC = blocks per CU the register/LDS budget is sized for.
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG>
+__global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
-    constexpr int PA = BM / 32;     // float4 loads per thread for the A tile
-    constexpr int PB = BN / 32;
+    constexpr int LDSK = BK + 4;            // padded LDS row (144 B / 80 B): conflict-free ds_read_b128
+    constexpr int TPR = BK / 4;             // threads (float4) per tile row
+    constexpr int RPP = 256 / TPR;          // rows staged per pass of the 256 threads
+    constexpr int PA = BM / RPP;            // float4 loads per thread for the A tile
+    constexpr int PB = BN / RPP;
     static_assert(WR * WC == 4, "4 waves");
+    static_assert(BK == 16 || BK == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDSK]
@@ -84,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give the 8 blocks that follow
@@ -100,126 +116,160 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     const int m0 = mt * BM, n0 = nt * BN;
     const long long z = blockIdx.z;
 
-    const int lrow = tid >> 3;          // 0..31: row inside a 32-row pass
-    const int c4 = (tid & 7) * 4;       // k offset of this thread's float4
+    const int lrow = tid / TPR;         // row inside a staging pass
+    const int c4 = (tid % TPR) * 4;     // k offset of this thread's float4
+    const int li = lane & 31, lh = lane >> 5;
 
-    // per-thread A rows: sequence position for shift bounds
+    // ---- accumulators start from bias (+ the previous output value for read-modify-write epilogues), so the
+    //      epilogue is a pure store and the old values are fetched under the first tile's load latency
+    const float* bias = g.bias ? g.bias + z * g.strideBiasZ : nullptr;
+    const int rbase = m0 + wr * RT * 32 + 4 * lh;
+    const int cbase = n0 + wc * CT * 32 + li;
+    // the output side (out0 / out1) is uniform per block: `split` is a multiple of BN or >= N (checked at launch)
+    const bool second = n0 >= g.split;
+    float* const outp = (second ? g.out1 : g.out0) + z * g.strideOutZ;
+    const long long ldo = second ? g.ld1 : g.ld0;
+    const int ncol0 = second ? cbase - g.split : cbase;     // this lane's first output column on that side
+    f32x16 acc[RT][CT];
+    {
+        float bv[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) bv[j] = (bias && cbase + j * 32 < g.N) ? bias[cbase + j * 32] : 0.f;
+        const bool rmw = g.mode == EPI_LINEAR && (second ? g.acc1 : g.acc0);
+        if (rmw) {
+            // branch-free batch of dword buffer loads (rows >= M and columns >= N read as 0), one wait for all
+            const __amdgpu_buffer_rsrc_t rsO = make_rsrc(outp + (long long)(m0 + wr * RT * 32) * ldo);
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = 4 * lh + i * 32 + (r & 3) + 8 * (r >> 2);      // row inside the wave's rows
+                        const bool ok = (m0 + wr * RT * 32 + rl < g.M) && (cbase + j * 32 < g.N);
+                        const unsigned off = ok ? (unsigned)((rl * (int)ldo + ncol0 + j * 32) * 4) : OOB;
+                        acc[i][j][r] = bv[j] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, off, 0, 0));
+                    }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
+        }
+    }
+
+    // ---- operand addressing
     int a_l[PA];
-    bool a_ok[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + p * 32 + lrow;
-        a_ok[p] = m < g.M;
-        a_l[p] = m % g.L;
+        const int m = m0 + p * RPP + lrow;
+        a_l[p] = m < g.M ? m % g.L : -0x40000000;      // rows past M never pass the [0, L) test below
     }
-    const float* Bt = g.Bt + z * g.strideBz;
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.Bt + z * g.strideBz + (long long)n0 * g.ldb);
+    unsigned b_off[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+        b_off[p] = (n0 + p * RPP + lrow < g.N) ? (unsigned)(((p * RPP + lrow) * (int)g.ldb + c4) * 4) : OOB;
 
     int nT = 0;
     for (int s = 0; s < g.nseg; ++s) nT += g.seg[s].kpad / BK;
 
-    f32x4 ra[PA], rb[PB];
-    f32x16 acc[RT][CT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    int s_cur = 0, kc_cur = 0, kglob = 0;   // tile iterator state (wave-uniform)
-
-    auto load_tile = [&]() {
+    // tile iterator (wave-uniform): current segment parameters live in registers, refreshed only at a crossing
+    int s_cur = 0, kc_cur = 0, kglob = 0;
+    int seg_k = 0, seg_kpad = 0;
+    __amdgpu_buffer_rsrc_t rsA;
+    unsigned a_off[PA];
+    auto enter_segment = [&]() {
         const ASeg sg = g.seg[s_cur];
-        const int kk = kc_cur * BK + c4;
-        const bool kok = kk < sg.k;
-        const float* base = sg.ptr + z * g.strideAz;
+        seg_k = sg.k;
+        seg_kpad = sg.kpad;
+        rsA = make_rsrc(sg.ptr + z * g.strideAz + ((long long)m0 + sg.shift) * sg.ld);
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            const int m = m0 + p * 32 + lrow;
             const int l2 = a_l[p] + sg.shift;
-            const bool ok = a_ok[p] && kok && l2 >= 0 && l2 < g.L;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(base + (long long)(m + sg.shift) * sg.ld + kk);
-            ra[p] = v;
+            a_off[p] = (l2 >= 0 && l2 < g.L) ? (unsigned)(((p * RPP + lrow) * (int)sg.ld + c4) * 4) : OOB;
         }
+    };
+
+    f32x4 ra[PA], rb[PB];
+    auto load_tile = [&]() {
+        const unsigned kb = (unsigned)(kc_cur * BK * 4);
+        const bool kok = kc_cur * BK + c4 < seg_k;
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int n = n0 + p * 32 + lrow;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < g.N) v = *reinterpret_cast<const f32x4*>(Bt + (long long)n * g.ldb + kglob + c4);
-            rb[p] = v;
-        }
-        // advance iterator
+        for (int p = 0; p < PA; ++p) ra[p] = buf_load4(rsA, kok ? a_off[p] + kb : OOB);
+        const unsigned kg = (unsigned)(kglob * 4);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rb[p] = buf_load4(rsB, b_off[p] + kg);
         kglob += BK;
-        if (++kc_cur * BK >= sg.kpad) { kc_cur = 0; ++s_cur; }
+        if (++kc_cur * BK >= seg_kpad) {
+            kc_cur = 0;
+            if (++s_cur < g.nseg) enter_segment();
+        }
     };
     auto store_tile = [&](int buf) {
         float* a = As + buf * BM * LDSK;
         float* b = Bs + buf * BN * LDSK;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(a + (p * 32 + lrow) * LDSK + c4) = ra[p];
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(a + (p * RPP + lrow) * LDSK + c4) = ra[p];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(b + (p * 32 + lrow) * LDSK + c4) = rb[p];
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(b + (p * RPP + lrow) * LDSK + c4) = rb[p];
+    };
+    auto compute_chunk = [&](int buf, int k8) {
+        const float* a = As + buf * BM * LDSK + (wr * RT * 32 + li) * LDSK + lh * 4 + k8 * 8;
+        const float* b = Bs + buf * BN * LDSK + (wc * CT * 32 + li) * LDSK + lh * 4 + k8 * 8;
+        f32x4 fa[RT], fb[CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
     };
 
-    const int li = lane & 31, lh = lane >> 5;
-    auto compute = [&](int buf) {
-        const float* a = As + buf * BM * LDSK + (wr * RT * 32 + li) * LDSK + lh * 4;
-        const float* b = Bs + buf * BN * LDSK + (wc * CT * 32 + li) * LDSK + lh * 4;
-#pragma unroll
-        for (int k8 = 0; k8 < BK / 8; ++k8) {
-            f32x4 fa[RT], fb[CT];
-#pragma unroll
-            for (int i = 0; i < RT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK + k8 * 8);
-#pragma unroll
-            for (int j = 0; j < CT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK + k8 * 8);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int j = 0; j < CT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
-        }
-    };
-
+    enter_segment();
     load_tile();
     store_tile(0);
     __syncthreads();
+    // Steady state: the next tile's global loads are issued first, three quarters of the MFMAs run on the current LDS
+    // buffer while they land, then the staged registers go to the other LDS buffer (last read one barrier ago) and the
+    // last quarter of the MFMAs covers those writes.  One barrier per K step.
     for (int t = 0; t < nT; ++t) {
         const bool more = t + 1 < nT;
+        const int buf = t & 1;
         if (more) load_tile();
-        compute(t & 1);
-        if (more) store_tile((t + 1) & 1);
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8 - 1; ++k8) compute_chunk(buf, k8);
+        if (more) store_tile(buf ^ 1);
+        compute_chunk(buf, BK / 8 - 1);
         __syncthreads();
     }
 
     // ---------------- epilogue ----------------
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const float* bias = g.bias ? g.bias + z * g.strideBiasZ : nullptr;
-    const int rbase = m0 + wr * RT * 32 + 4 * lh;
-    const int cbase = n0 + wc * CT * 32 + li;
     if constexpr (WC == 1 && CT % 2 == 0) {
         if (g.mode == EPI_GATE) {
             // columns [n0, n0 + BN/2) hold the tanh pre-activations, [n0 + BN/2, n0 + BN) the matching sigmoid
             // pre-activations (weight rows are permuted at load time); output channel = nt * BN/2 + local column.
             constexpr int H = CT / 2;
-            float* out = g.out0 + z * g.strideOutZ;
+            float* out = outp;
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < H; ++j) {
-                    const int col_t = cbase + j * 32;
-                    const int col_s = col_t + (BN / 2);
-                    const float bt = bias ? bias[col_t] : 0.f;
-                    const float bs = bias ? bias[col_s] : 0.f;
                     const int ch = nt * (BN / 2) + j * 32 + li;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
                         if (m < g.M) {
-                            const float tv = tanhf(acc[i][j][r] + bt);
-                            const float sv = sigmoid_exact(acc[i][j + H][r] + bs);
+                            const float tv = tanhf(acc[i][j][r]);
+                            const float sv = sigmoid_exact(acc[i][j + H][r]);
                             out[(long long)m * g.ld0 + ch] = tv * sv;
                         }
                     }
@@ -233,41 +283,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         for (int j = 0; j < CT; ++j) {
             const int n = cbase + j * 32;
             if (n >= g.N) continue;
-            const float bv = bias ? bias[n] : 0.f;
-            const bool second = n >= g.split;
-            float* out = (second ? g.out1 : g.out0) + z * g.strideOutZ;
-            const long long ld = second ? g.ld1 : g.ld0;
-            const int accf = second ? g.acc1 : g.acc0;
-            const int nc = second ? n - g.split : n;
+            const int nc = ncol0 + j * 32;
             const float ab = g.altbias ? g.altbias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (m < g.M) {
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r];
                     if (g.rowmask) {
                         const bool on = g.rowmask[m] != 0;
-                        if (g.mask_out) v = on ? v : 0.f;
-                        else v = on ? v : ab;
+                        v = on ? v : (g.mask_out ? 0.f : ab);
                     }
-                    v = act_apply(v, g.act);
-                    float* p = out + (long long)m * ld + nc;
-                    if (accf) v += *p;
-                    *p = v;
+                    outp[(long long)m * ldo + nc] = act_apply(v, g.act);
                 }
             }
         }
 }
 
-template <int WR, int WC, int RT, int CT>
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
+    constexpr int LDSK = BK + 4;
     const int numNt = (g.N + BN - 1) / BN;
     const int numMt = (g.M + BM - 1) / BM;
     const int numMt8 = (numMt + 7) / 8 * 8;
     const size_t lds = (size_t)2 * (BM + BN) * LDSK * sizeof(float);
-    auto kern = gemm_f32_kernel<WR, WC, RT, CT>;
+    if (g.split < g.N && g.split % BN != 0) return hipErrorInvalidValue;     // output side must be uniform per block
+    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -280,7 +323,14 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
 }
 
 // Tile configurations: BIG = 256x128 (WN layers, upsampling); SMALL = 64x64 (Tacotron2-sized problems).
-inline hipError_t gemm_big(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<4, 1, 2, 4>(g, bz, s); }
-inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1>(g, bz, s); }
+enum { TAG_GENERIC = 0, TAG_WN_IN = 1, TAG_WN_RES_SKIP = 2 };
+#ifndef TTS_WN_BK
+#define TTS_WN_BK 16
+#define TTS_WN_OCC 2
+#endif
+inline hipError_t gemm_big(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<4, 1, 2, 4, 32, 1, TAG_GENERIC>(g, bz, s); }
+inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<4, 1, 2, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN>(g, 1, s); }
+inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<4, 1, 2, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_RES_SKIP>(g, 1, s); }
+inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1, 32, 1, TAG_GENERIC>(g, bz, s); }
 
 }  // namespace ttsgemm

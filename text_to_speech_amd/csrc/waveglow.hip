@@ -416,7 +416,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.ld0 = C;
             g.split = 2 * C;
             timing_begin(e, 0);
-            HIPCHK(e, gemm_big(g, 1, st));
+            HIPCHK(e, gemm_wn_in(g, st));
             timing_end(e);
 
             GemmArgs r{};
@@ -446,7 +446,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 r.out1 = nullptr;
             }
             timing_begin(e, 1);
-            HIPCHK(e, gemm_big(r, 1, st));
+            HIPCHK(e, gemm_wn_res_skip(r, st));
             timing_end(e);
         }
         const bool early = (k % 4 == 0) && k > 0;
