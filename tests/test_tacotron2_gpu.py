@@ -1,0 +1,117 @@
+"""GPU parity: HIP Tacotron2 (through the C ABI) vs the numpy oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): mel spectrogram within 1e-3 abs (fp32); integer outputs (lengths) exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL = 1e-3
+
+
+def _tokens(B, Tin, lens, seed=0):
+    rng = np.random.default_rng(seed)
+    tok = rng.integers(1, 148, (B, Tin)).astype(np.int32)
+    for b, n in enumerate(lens):
+        tok[b, n:] = 0
+    return tok
+
+
+def _check(out, ref, steps=None):
+    assert np.array_equal(out.lengths, ref.lengths), (out.lengths, ref.lengths)
+    for name in ('decoder_output', 'mel', 'stop_tokens', 'attention_weights'):
+        a, r = getattr(out, name), getattr(ref, name)
+        assert a.shape == r.shape, name
+        err = np.abs(a - r).max()
+        print(f'{name}: max abs err {err:.3e}')
+        assert err <= MEL_TOL, name
+
+
+def _engine(weights):
+    from text_to_speech_amd.engine import HipEngine
+    eng = HipEngine(0)
+    eng.load_state(weights)
+    eng.finalize()
+    return eng
+
+
+def test_fixed_steps_deterministic_b1(gpu_engine, taco_weights, taco_cfg):
+    from oracle import tacotron2_ref
+    tok = _tokens(1, 24, [24])
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=40, early_stopping=False)
+    out = gpu_engine.tacotron2_infer(tok, max_len=40, early_stopping=False)
+    assert gpu_engine.last_steps == 40
+    _check(out, ref)
+
+
+def test_ragged_batch_with_dropout_masks(gpu_engine, taco_weights, taco_cfg):
+    from oracle import tacotron2_ref
+    B, Tin, T = 3, 37, 45
+    tok = _tokens(B, Tin, [37, 20, 9], seed=1)
+    masks = (np.random.default_rng(3).random((B, T, 2, 256)) >= 0.5).astype(np.float32) * 2.0
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=T, early_stopping=False, prenet_masks=masks)
+    out = gpu_engine.tacotron2_infer(tok, max_len=T, early_stopping=False, prenet_masks=masks)
+    _check(out, ref)
+    # masked softmax: padded token positions get exactly zero attention
+    assert np.all(out.attention_weights[1, :, 20:] == 0)
+    np.testing.assert_allclose(out.attention_weights.sum(-1), 1.0, atol=1e-5)
+
+
+def test_early_stopping_lengths(taco_cfg):
+    """Rows stop at different steps; loop ends when all have fired; `lengths` excludes the firing frame (:664-665)."""
+    from oracle import tacotron2_ref
+    from text_to_speech_amd import weights
+    # gate kernel x10 and bias -6.55 script staggered stops: the oracle gives lengths [7, 3, 5, 37] (two graph chunks)
+    w = weights.synth_tacotron2(taco_cfg, seed=1234, gate_bias=-6.55)
+    w['tacotron2/decoder/gate_output/kernel'] = w['tacotron2/decoder/gate_output/kernel'] * 10
+    tok = _tokens(4, 30, [30, 25, 18, 12], seed=2)
+    ref = tacotron2_ref.infer(tok, w, taco_cfg, max_length=100, early_stopping=True)
+    print('oracle lengths', ref.lengths)
+    assert ref.lengths.max() < 99 and len(set(ref.lengths.tolist())) > 1, 'test weights must give staggered stops'
+    eng = _engine(w)
+    try:
+        out = eng.tacotron2_infer(tok, max_len=100, early_stopping=True)
+        assert eng.last_steps == int(ref.lengths.max()) + 1
+        _check(out, ref)
+        # frames after the loop ended are untouched zeros
+        assert np.all(out.decoder_output[:, eng.last_steps:] == 0)
+    finally:
+        eng.close()
+
+
+def test_speaker_embedding_enc768():
+    from oracle import tacotron2_ref
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import Tacotron2Config
+    cfg = Tacotron2Config(speaker_embedding_dim=256)
+    w = weights.synth_tacotron2(cfg, seed=99)
+    tok = _tokens(2, 21, [21, 15], seed=4)
+    spk = np.random.default_rng(5).standard_normal((2, 256)).astype(np.float32)
+    spk /= np.linalg.norm(spk, axis=1, keepdims=True)
+    ref = tacotron2_ref.infer(tok, w, cfg, speaker_embedding=spk, max_length=30, early_stopping=False)
+    eng = _engine(w)
+    try:
+        out = eng.tacotron2_infer(tok, speaker=spk, max_len=30, early_stopping=False)
+        _check(out, ref)
+    finally:
+        eng.close()
+
+
+def test_attention_window(gpu_engine, taco_weights, taco_cfg):
+    from oracle import tacotron2_ref
+    tok = _tokens(2, 40, [40, 33], seed=6)
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=25, early_stopping=False,
+                              attn_mask_win_len=12, attn_mask_offset=0.5)
+    out = gpu_engine.tacotron2_infer(tok, max_len=25, early_stopping=False, attn_mask_win_len=12, attn_mask_offset=6)
+    _check(out, ref)
+
+
+def test_batch_larger_than_lstm_chunk(gpu_engine, taco_weights, taco_cfg):
+    """B = 11 exercises the second batch chunk (NB = 8) of the LSTM step kernel."""
+    from oracle import tacotron2_ref
+    lens = [16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6]
+    tok = _tokens(11, 16, lens, seed=7)
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=12, early_stopping=False)
+    out = gpu_engine.tacotron2_infer(tok, max_len=12, early_stopping=False)
+    _check(out, ref)

@@ -1,5 +1,612 @@
-// tacotron2.hip -- placeholder until the decoder kernels land (keeps the C ABI complete and loud).
+// tacotron2.hip -- Tacotron2 inference on gfx950: encoder, autoregressive decoder, postnet.
+//
+// Replaces /root/reference/architectures/tacotron2_arch.py:866-925 (Tacotron2.infer), :609-749 (Tacotron2Decoder.infer
+// and its while_loop body), :422-486 (Tacotron2DecoderCell.call), :188-203 (prenet), :235-333 (encoder), :214-232
+// (postnet) and architectures/layers/location_sensitive_attention.py:96-186.
+//
+// Decoder step = 6 launches, weights streamed once per step (HBM/Infinity-Cache bound):
+//   prenet        frame[B,80] -> p2[B,256]                      grid (B, 8)
+//   lstm_step<KS> attention LSTM: x = [p2 | ctx | h_att] (K = 256*KS), 4 gate rows per wave, weights in registers,
+//                 x staged in LDS, lane-halving shuffle reduction, fused cell update                 grid 256
+//   energies      q = h_att Wq (per block), location features, e = v . tanh(q + pm + loc)            grid (B, Tin/16)
+//   softmax_ctx   masked softmax over Tin (wave shuffles), ctx = w @ memory, cum += w, history       grid (B, enc/128)
+//   lstm_step<KS> decoder LSTM: x = [h_att | ctx | h_dec]                                             grid 256
+//   project       frame / stop token, finished / lengths bookkeeping, output scatter                 grid (21) x B rows
+// The step index is `*t0 + j` (j baked into the launch), so 32 steps form one hipGraph that is replayed per chunk;
+// every kernel returns immediately once all rows are finished (device flag), which keeps the reference's
+// "stop as soon as every row has fired" semantics (:625-627) without a host round trip per step.
 #include "engine.h"
+#include "gemm_f32.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+using namespace ttsgemm;
+
+namespace {
+
+constexpr int NB = 8;                 // batch rows processed together by the LSTM kernel (zero padded)
+constexpr int PRE = 256, ARNN = 1024, DRNN = 1024, ATT = 128, NMEL = 80, LOCK = 31;
+constexpr int CHUNK = 32;             // decoder steps per hipGraph replay
+
+struct DecState {                     // device-resident loop state (one per call)
+    int t0;                           // first step of the current chunk
+    int n_finished;                   // rows whose stop token has fired
+    int steps_run;                    // loop iterations executed so far
+    int B, max_len, early_stop;
+};
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// LSTM: Wp[4*u + g][k] = k < kin ? kernel[k][g*U + u] : recurrent[k - kin][g*U + u]
+__global__ void pack_lstm_kernel(const float* __restrict__ kernel, const float* __restrict__ rec,
+                                 const float* __restrict__ bias, float* __restrict__ Wp, float* __restrict__ bp,
+                                 int kin, int U) {
+    const int K = kin + U;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long long)4 * U * K) {
+        const int r = (int)(idx / K), k = (int)(idx % K);
+        const int u = r >> 2, gt = r & 3;
+        const int col = gt * U + u;
+        Wp[idx] = k < kin ? kernel[(long long)k * 4 * U + col] : rec[(long long)(k - kin) * 4 * U + col];
+    }
+    if (idx < 4 * U) {
+        const int u = (int)idx >> 2, gt = (int)idx & 3;
+        bp[idx] = bias[gt * U + u];
+    }
+}
+
+// dst[n][k] = src[k][n]   (Dense kernel [in][out] -> out-major rows)
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int N, int ldd) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)K * N) return;
+    const int n = (int)(idx / K), k = (int)(idx % K);
+    dst[(long long)n * ldd + k] = src[(long long)k * N + n];
+}
+
+// ------------------------------------------------------------------------------------------------ encoder kernels
+__global__ void embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, float* __restrict__ x,
+                             uint8_t* __restrict__ mask, int n_rows, int vocab) {
+    const int row = blockIdx.x;
+    if (row >= n_rows) return;
+    int id = tok[row];
+    const bool on = id != 0;
+    if (id < 0 || id >= vocab) id = 0;
+    if (threadIdx.x == 0) mask[row] = on ? 1 : 0;
+    for (int c = threadIdx.x; c < 512; c += blockDim.x) x[(long long)row * 512 + c] = on ? emb[(long long)id * 512 + c] : 0.f;
+}
+
+// Masked (Bi)LSTM recurrence, one block per (direction, batch row); thread = gate column (Keras order gate*256 + u).
+// xproj already holds x @ kernel + bias for every step (one GEMM), so a step is h @ recurrent + pointwise.
+__global__ __launch_bounds__(1024) void bilstm_kernel(const float* __restrict__ xproj, const float* __restrict__ rec_f,
+                                                      const float* __restrict__ rec_b,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ memory,
+                                                      int Tin, int enc) {
+    __shared__ float h_s[256];
+    __shared__ float g_s[1024];
+    const int dir = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
+    const float* U = dir == 0 ? rec_f : rec_b;
+    float cstate = 0.f;
+    if (c < 256) h_s[c] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < Tin; ++s) {
+        const int t = dir == 0 ? s : Tin - 1 - s;
+        const long long row = (long long)b * Tin + t;
+        const bool on = mask[row] != 0;                 // block-uniform
+        if (on) {
+            float acc = xproj[row * 2048 + dir * 1024 + c];
+#pragma unroll 8
+            for (int k = 0; k < 256; ++k) acc = fmaf(h_s[k], U[k * 1024 + c], acc);
+            g_s[c] = acc;
+        }
+        __syncthreads();
+        if (c < 256) {
+            float hv = 0.f;
+            if (on) {
+                const float ig = sigmoid_exact(g_s[c]), fg = sigmoid_exact(g_s[256 + c]);
+                const float gg = tanhf(g_s[512 + c]), og = sigmoid_exact(g_s[768 + c]);
+                cstate = fg * cstate + ig * gg;
+                hv = og * tanhf(cstate);
+                h_s[c] = hv;
+            }
+            memory[row * enc + dir * 256 + c] = hv;     // padded positions: 0 (state carried through)
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void speaker_concat_kernel(const float* __restrict__ spk, const uint8_t* __restrict__ mask,
+                                      float* __restrict__ memory, int Tin, int enc, int spk_dim, long long rows) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * spk_dim) return;
+    const long long row = idx / spk_dim;
+    const int c = (int)(idx % spk_dim);
+    const int b = (int)(row / Tin);
+    memory[row * enc + 512 + c] = mask[row] ? spk[(long long)b * spk_dim + c] : 0.f;
+}
+
+__global__ void enc_len_kernel(const uint8_t* __restrict__ mask, int* __restrict__ enc_len, int Tin) {
+    const int b = blockIdx.x;
+    int n = 0;
+    for (int t = threadIdx.x; t < Tin; t += 64) n += mask[(long long)b * Tin + t];
+    for (int s = 32; s >= 1; s >>= 1) n += __shfl_xor(n, s, 64);
+    if (threadIdx.x == 0) enc_len[b] = n;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder kernels
+__device__ __forceinline__ bool step_done(const DecState* st, int j, int& t) {
+    t = st->t0 + j;
+    if (t >= st->max_len) return true;
+    return st->early_stop && st->n_finished >= st->B;
+}
+
+// prenet: grid (B, 8).  Every block recomputes layer 1 (80 -> 256) for its row, then its 32 outputs of layer 2.
+__global__ __launch_bounds__(256) void prenet_kernel(const DecState* __restrict__ st, int j,
+                                                     const float* __restrict__ frame, const float* __restrict__ w0,
+                                                     const float* __restrict__ w1, const float* __restrict__ masks,
+                                                     float* __restrict__ p2) {
+    int t;
+    if (step_done(st, j, t)) return;
+    __shared__ float f_s[NMEL];
+    __shared__ float p1_s[PRE];
+    const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    if (tid < NMEL) f_s[tid] = frame[b * NMEL + tid];
+    __syncthreads();
+    {
+        const float* w = w0 + tid * NMEL;                       // w0 is out-major [256][80]
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < NMEL; ++k) acc = fmaf(f_s[k], w[k], acc);
+        acc = fmaxf(acc, 0.f);
+        if (masks) acc *= masks[(((long long)b * st->max_len + t) * 2 + 0) * PRE + tid];
+        p1_s[tid] = acc;
+    }
+    __syncthreads();
+    {   // 32 outputs per block, 8 lanes per output
+        const int o = part * 32 + (tid >> 3), sub = tid & 7;
+        const float* w = w1 + o * PRE + sub * 32;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) acc = fmaf(p1_s[sub * 32 + k], w[k], acc);
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (sub == 0) {
+            acc = fmaxf(acc, 0.f);
+            if (masks) acc *= masks[(((long long)b * st->max_len + t) * 2 + 1) * PRE + o];
+            p2[b * PRE + o] = acc;
+        }
+    }
+}
+
+// One LSTM step.  K = 256 * KS inputs = [seg0 | seg1 | seg2(recurrent h)]; block = 4 waves = 4 hidden units; each wave
+// keeps its 4 gate rows (i, f, c, o of one unit) in registers (KS float4 per row per lane), x for NB batch rows is staged
+// in LDS, and the 4 x NB partial sums are reduced with a lane-halving exchange (32 shuffles instead of 192).
+template <int KS>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restrict__ st, int j,
+                                                        const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                        const float* __restrict__ s0, int n0,
+                                                        const float* __restrict__ s1, int n1,
+                                                        const float* __restrict__ h_old, float* __restrict__ h_new,
+                                                        float* __restrict__ c_state, int B, int U) {
+    int t;
+    if (step_done(st, j, t)) return;
+    constexpr int K = 256 * KS;
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // [NB][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = blockIdx.x * 4 + wave;
+    // weights -> registers (issued first: the longest-latency stream)
+    f32x4 w[4][KS];
+    const float* wrow = Wp + (long long)(4 * u) * K + lane * 4;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int i = 0; i < KS; ++i) w[gt][i] = *reinterpret_cast<const f32x4*>(wrow + (long long)gt * K + i * 256);
+
+    for (int b0 = 0; b0 < B; b0 += NB) {
+        if (b0) __syncthreads();
+        // stage x[b][:] = [s0[b] | s1[b] | h_old[b]] for NB rows (zeros beyond B)
+        for (int idx = tid; idx < NB * (K / 4); idx += 256) {
+            const int bb = idx / (K / 4), k = (idx % (K / 4)) * 4;
+            const int b = b0 + bb;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                if (k < n0) v = *reinterpret_cast<const f32x4*>(s0 + (long long)b * n0 + k);
+                else if (k < n0 + n1) v = *reinterpret_cast<const f32x4*>(s1 + (long long)b * n1 + (k - n0));
+                else v = *reinterpret_cast<const f32x4*>(h_old + (long long)b * U + (k - n0 - n1));
+            }
+            *reinterpret_cast<f32x4*>(xs + bb * K + k) = v;
+        }
+        __syncthreads();
+        float acc[4 * NB];                                           // index gate * NB + b
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KS; ++i)
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + bb * K + i * 256 + lane * 4);
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    float a = acc[gt * NB + bb];
+                    a = fmaf(xv[0], w[gt][i][0], a);
+                    a = fmaf(xv[1], w[gt][i][1], a);
+                    a = fmaf(xv[2], w[gt][i][2], a);
+                    a = fmaf(xv[3], w[gt][i][3], a);
+                    acc[gt * NB + bb] = a;
+                }
+            }
+        // lane-halving reduction: after masks 32,16,8,4,2 lane l holds output index (l >> 1) & 31, then mask 1
+#pragma unroll
+        for (int half = 16, m = 32; half >= 1; half >>= 1, m >>= 1) {
+            const bool hi = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const float send = hi ? acc[i] : acc[i + half];
+                const float keep = hi ? acc[i + half] : acc[i];
+                acc[i] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        float v = acc[0] + __shfl_xor(acc[0], 1, 64);
+        // lane 2*(gate*NB + bb) holds gate pre-activation (without bias) of (gate, bb): gather the 4 gates per bb
+        const int src_b = (lane >> 1) & (NB - 1);
+        const float gi = __shfl(v, 2 * (0 * NB + src_b), 64);
+        const float gf = __shfl(v, 2 * (1 * NB + src_b), 64);
+        const float gg = __shfl(v, 2 * (2 * NB + src_b), 64);
+        const float go = __shfl(v, 2 * (3 * NB + src_b), 64);
+        if (lane < 2 * NB && (lane & 1) == 0) {
+            const int b = b0 + (lane >> 1);
+            if (b < B) {
+                const float ig = sigmoid_exact(gi + bp[4 * u + 0]);
+                const float fg = sigmoid_exact(gf + bp[4 * u + 1]);
+                const float cg = tanhf(gg + bp[4 * u + 2]);
+                const float og = sigmoid_exact(go + bp[4 * u + 3]);
+                const float cn = fg * c_state[(long long)b * U + u] + ig * cg;
+                c_state[(long long)b * U + u] = cn;
+                h_new[(long long)b * U + u] = og * tanhf(cn);
+            }
+        }
+    }
+}
+
+// energies: grid (B, ceil(Tin / 16)).  q = h_att @ Wq is recomputed per block (Wq^T is L2 resident); the location conv
+// (2 -> 32, k 31) and dense (32 -> 128) are folded at load time into one [62][128] map (no nonlinearity in between).
+__global__ __launch_bounds__(256) void energies_kernel(const DecState* __restrict__ st, int j,
+                                                       const float* __restrict__ h_att, const float* __restrict__ wq_t,
+                                                       const float* __restrict__ wloc, const float* __restrict__ v_w,
+                                                       const float* __restrict__ pm, const float* __restrict__ w_prev,
+                                                       const float* __restrict__ w_cum, float* __restrict__ energies,
+                                                       int Tin) {
+    int t;
+    if (step_done(st, j, t)) return;
+    __shared__ float h_s[ARNN];
+    __shared__ float q_s[2][ATT];
+    __shared__ float cat_s[2][16 + LOCK - 1];
+    __shared__ __attribute__((aligned(16))) float wl_s[2 * LOCK * ATT];
+    const int b = blockIdx.x, tc = blockIdx.y, tid = threadIdx.x;
+    const int tbase = tc * 16;
+    for (int k = tid; k < ARNN; k += 256) h_s[k] = h_att[(long long)b * ARNN + k];
+    for (int i = tid; i < 2 * LOCK * ATT; i += 256) wl_s[i] = wloc[i];
+    if (tid < 2 * (16 + LOCK - 1)) {
+        const int c = tid / (16 + LOCK - 1), p = tid % (16 + LOCK - 1);
+        const int tt = tbase + p - (LOCK / 2);
+        float v = 0.f;
+        if (tt >= 0 && tt < Tin) v = (c == 0 ? w_prev : w_cum)[(long long)b * Tin + tt];
+        cat_s[c][p] = v;
+    }
+    __syncthreads();
+    {   // q[a]: two K halves per output, wq_t is [1024][128] so consecutive threads read consecutive floats
+        const int a = tid & (ATT - 1), half = tid >> 7;
+        const float* w = wq_t + (long long)half * 512 * ATT + a;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 512; ++k) acc = fmaf(h_s[half * 512 + k], w[(long long)k * ATT], acc);
+        q_s[half][a] = acc;
+    }
+    __syncthreads();
+    // thread (tl, al): position tbase + tl, attention dims al*8 .. al*8+7
+    const int tl = tid >> 4, al = tid & 15;
+    const int tt = tbase + tl;
+    float loc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) loc[i] = 0.f;
+    for (int jj = 0; jj < LOCK; ++jj)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float cv = cat_s[c][tl + jj];
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl_s + (jj * 2 + c) * ATT + al * 8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl_s + (jj * 2 + c) * ATT + al * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                loc[i] = fmaf(cv, w0[i], loc[i]);
+                loc[4 + i] = fmaf(cv, w1[i], loc[4 + i]);
+            }
+        }
+    float e = 0.f;
+    if (tt < Tin) {
+        const float* pmr = pm + ((long long)b * Tin + tt) * ATT + al * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = al * 8 + i;
+            const float qv = q_s[0][a] + q_s[1][a];
+            e = fmaf(v_w[a], tanhf(qv + pmr[i] + loc[i]), e);
+        }
+    }
+    e += __shfl_xor(e, 1, 64);
+    e += __shfl_xor(e, 2, 64);
+    e += __shfl_xor(e, 4, 64);
+    e += __shfl_xor(e, 8, 64);
+    if (al == 0 && tt < Tin) energies[(long long)b * Tin + tt] = e;
+}
+
+// softmax + context: grid (B, enc / 128).  Each block redoes the (cheap) masked softmax over Tin, then its 128 context
+// columns; block y == 0 also updates w_prev / w_cum, the alignment history and main_attention (argmax).
+__global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __restrict__ st, int j,
+                                                          const float* __restrict__ energies,
+                                                          const uint8_t* __restrict__ mask,
+                                                          const int* __restrict__ enc_len, int win_len, int win_off,
+                                                          const int* __restrict__ main_att_old,
+                                                          int* __restrict__ main_att, const float* __restrict__ memory,
+                                                          float* __restrict__ w_prev, float* __restrict__ w_cum,
+                                                          float* __restrict__ ctx, float* __restrict__ attn_hist,
+                                                          int Tin, int enc) {
+    int t;
+    if (step_done(st, j, t)) return;
+    extern __shared__ float sm[];                 // [Tin] weights + 2*128 partials
+    float* w_s = sm;
+    float* part = sm + Tin;
+    __shared__ float red_s[8];
+    __shared__ int redi_s[4];
+    const int b = blockIdx.x, ec = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // attention window (tacotron2_arch.py:630-638)
+    int lo = 0, hi = Tin;
+    if (win_len > 0) {
+        int center = max(main_att_old[b], win_off);      // previous step's argmax (ping-pong: other blocks write the new one)
+        center = min(center, enc_len[b] - win_len + win_off);
+        lo = center - win_off;
+        hi = center - win_off + win_len;          // inclusive upper bound
+    }
+    float mx = -INFINITY;
+    for (int tt = tid; tt < Tin; tt += 256) {
+        bool on = mask[(long long)b * Tin + tt] != 0;
+        if (win_len > 0) on = on && tt >= lo && tt <= hi;
+        const float e = on ? energies[(long long)b * Tin + tt] : -INFINITY;
+        w_s[tt] = e;
+        mx = fmaxf(mx, e);
+    }
+    for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+    if (lane == 0) red_s[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+    float sum = 0.f;
+    for (int tt = tid; tt < Tin; tt += 256) {
+        const float p = expf(w_s[tt] - mx);       // exp(-inf) = 0 at masked positions
+        w_s[tt] = p;
+        sum += p;
+    }
+    for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s, 64);
+    if (lane == 0) red_s[4 + wave] = sum;
+    __syncthreads();
+    sum = (red_s[4] + red_s[5]) + (red_s[6] + red_s[7]);
+    for (int tt = tid; tt < Tin; tt += 256) w_s[tt] = w_s[tt] / sum;
+    __syncthreads();
+    // context columns: 128 per block, two halves of Tin per column
+    {
+        const int e = ec * 128 + (tid & 127), half = tid >> 7;
+        const int t_lo = half * ((Tin + 1) / 2), t_hi = half ? Tin : (Tin + 1) / 2;
+        const float* mem = memory + (long long)b * Tin * enc + e;
+        float acc = 0.f;
+        for (int tt = t_lo; tt < t_hi; ++tt) acc = fmaf(w_s[tt], mem[(long long)tt * enc], acc);
+        part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) ctx[(long long)b * enc + ec * 128 + tid] = part[tid] + part[128 + tid];
+    if (ec == 0) {
+        float best = -1.f;
+        int besti = 0x7fffffff;
+        for (int tt = tid; tt < Tin; tt += 256) {
+            const float p = w_s[tt];
+            w_prev[(long long)b * Tin + tt] = p;
+            w_cum[(long long)b * Tin + tt] += p;
+            if (attn_hist) attn_hist[((long long)b * st->max_len + t) * Tin + tt] = p;
+            if (p > best) { best = p; besti = tt; }          // strided order keeps the lowest index per thread
+        }
+        for (int s = 32; s >= 1; s >>= 1) {
+            const float ob = __shfl_xor(best, s, 64);
+            const int oi = __shfl_xor(besti, s, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) { red_s[wave] = best; redi_s[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w2 = 1; w2 < 4; ++w2)
+                if (red_s[w2] > best || (red_s[w2] == best && redi_s[w2] < besti)) { best = red_s[w2]; besti = redi_s[w2]; }
+            main_att[b] = besti;
+        }
+    }
+}
+
+// projection + stop token + bookkeeping.  grid = 21 blocks x 4 waves = 84 waves >= 81 outputs; wave `o` computes
+// output column o (0..79 mel, 80 gate) for every batch row from cell_out = [h_dec | ctx].
+__global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st, int j, const float* __restrict__ h_dec,
+                                                      const float* __restrict__ ctx, const float* __restrict__ pw,
+                                                      const float* __restrict__ pb, float* __restrict__ frame,
+                                                      float* __restrict__ dec_out, float* __restrict__ stop_out,
+                                                      int* __restrict__ finished, int* __restrict__ lengths, int B,
+                                                      int enc) {
+    int t;
+    if (step_done(st, j, t)) return;
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o > NMEL) return;
+    const int K = DRNN + enc;
+    const float* w = pw + (long long)o * K;
+    for (int b = 0; b < B; ++b) {
+        float acc = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+            const f32x4 xv = k < DRNN ? *reinterpret_cast<const f32x4*>(h_dec + (long long)b * DRNN + k)
+                                      : *reinterpret_cast<const f32x4*>(ctx + (long long)b * enc + (k - DRNN));
+            acc = fmaf(xv[0], wv[0], acc);
+            acc = fmaf(xv[1], wv[1], acc);
+            acc = fmaf(xv[2], wv[2], acc);
+            acc = fmaf(xv[3], wv[3], acc);
+        }
+        for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+        if (lane == 0) {
+            const float v = acc + pb[o];
+            if (o < NMEL) {
+                frame[b * NMEL + o] = v;
+                dec_out[((long long)b * st->max_len + t) * NMEL + o] = v;
+            } else {
+                const float sp = sigmoid_exact(v);
+                stop_out[(long long)b * st->max_len + t] = sp;
+                // finished |= stop > 0.5 ; lengths += !finished      (tacotron2_arch.py:664-665)
+                int fin = finished[b];
+                if (!fin && sp > 0.5f) {
+                    fin = 1;
+                    finished[b] = 1;
+                    atomicAdd(&st->n_finished, 1);
+                }
+                if (!fin) lengths[b] += 1;
+                if (b == B - 1) st->steps_run = t + 1;
+            }
+        }
+    }
+}
+
+__global__ void advance_chunk_kernel(DecState* st) { st->t0 += CHUNK; }
+
+__global__ void init_state_kernel(DecState* st, int B, int max_len, int early_stop) {
+    st->t0 = 0;
+    st->n_finished = 0;
+    st->steps_run = 0;
+    st->B = B;
+    st->max_len = max_len;
+    st->early_stop = early_stop;
+}
+
+// dec_mask[b][t] = t <= lengths[b]   (tacotron2_arch.py:745, per row); masked copy of decoder_output for the postnet
+__global__ void dec_mask_kernel(const int* __restrict__ lengths, const float* __restrict__ dec_out,
+                                uint8_t* __restrict__ dmask, float* __restrict__ xm, int max_len, long long rows) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * NMEL) return;
+    const long long row = idx / NMEL;
+    const int b = (int)(row / max_len), t = (int)(row % max_len);
+    const bool on = t <= lengths[b];
+    if (idx % NMEL == 0) dmask[row] = on ? 1 : 0;
+    xm[idx] = on ? dec_out[idx] : 0.f;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) o[idx] = a[idx] + b[idx];
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, cap = 0;
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) / 256 * 256;
+        T* p = (T*)(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+int fold_conv_bn(tts_hip_engine* e, const std::string& conv, const std::string& norm, int cin, int cout, ConvBnDev* out,
+                 std::vector<void*>& allocs) {
+    const HostTensor* k = find_tensor(e, conv + "/kernel");
+    const HostTensor* b = find_tensor(e, conv + "/bias");
+    const HostTensor* ga = find_tensor(e, norm + "/gamma");
+    const HostTensor* be = find_tensor(e, norm + "/beta");
+    const HostTensor* mu = find_tensor(e, norm + "/moving_mean");
+    const HostTensor* va = find_tensor(e, norm + "/moving_variance");
+    if (!k || !b || !ga || !be || !mu || !va) return set_err(e, TTS_HIP_ENOTREADY, "missing tensors of %s", conv.c_str());
+    if (k->dims != std::vector<int64_t>{5, cin, cout} || (int)b->numel() != cout || (int)ga->numel() != cout)
+        return set_err(e, TTS_HIP_EINVAL, "unexpected shape for %s", conv.c_str());
+    const int cin_pad = (cin + 31) / 32 * 32;
+    out->cin = cin;
+    out->cin_pad = cin_pad;
+    out->cout = cout;
+    std::vector<float> Bt((size_t)cout * 5 * cin_pad, 0.f), bias(cout), alt(cout);
+    for (int o = 0; o < cout; ++o) {
+        // BatchNormalization inference: (x - mean) / sqrt(var + eps) * gamma + beta, eps = 1e-5 (tacotron2_arch.py:69,100)
+        const double s = (double)ga->data[o] / std::sqrt((double)va->data[o] + 1e-5);
+        bias[o] = (float)(((double)b->data[o] - (double)mu->data[o]) * s + (double)be->data[o]);
+        alt[o] = (float)((0.0 - (double)mu->data[o]) * s + (double)be->data[o]);      // BN(0): masked rows
+        for (int tap = 0; tap < 5; ++tap)
+            for (int c = 0; c < cin; ++c)
+                Bt[((size_t)o * 5 + tap) * cin_pad + c] = (float)((double)k->data[((size_t)tap * cin + c) * cout + o] * s);
+    }
+    int rc;
+    if ((rc = upload(e, Bt.data(), Bt.size(), &out->Bt, allocs))) return rc;
+    if ((rc = upload(e, bias.data(), bias.size(), &out->bias, allocs))) return rc;
+    return upload(e, alt.data(), alt.size(), &out->altbias, allocs);
+}
+
+int upload_transposed(tts_hip_engine* e, const HostTensor* t, int K, int N, int ldd, float** dst,
+                      std::vector<void*>& allocs) {
+    std::vector<float> tr((size_t)N * ldd, 0.f);
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) tr[(size_t)n * ldd + k] = t->data[(size_t)k * N + n];
+    return upload(e, tr.data(), tr.size(), dst, allocs);
+}
+
+int conv_gemm(tts_hip_engine* e, const ConvBnDev& cv, const float* x, int ldx, float* out, int M, int L,
+              const uint8_t* rowmask, int act, int mask_out) {
+    GemmArgs g{};
+    g.M = M;
+    g.N = cv.cout;
+    g.L = L;
+    g.nseg = 5;
+    for (int tap = 0; tap < 5; ++tap) g.seg[tap] = ASeg{x, ldx, tap - 2, cv.cin, cv.cin_pad};
+    g.Bt = cv.Bt;
+    g.ldb = 5ll * cv.cin_pad;
+    g.bias = cv.bias;
+    g.mode = EPI_LINEAR;
+    g.act = act;
+    g.split = cv.cout;
+    g.out0 = out;
+    g.ld0 = cv.cout;
+    g.rowmask = rowmask;
+    g.altbias = cv.altbias;
+    g.mask_out = mask_out;
+    HIPCHK(e, gemm_small(g, 1, e->stream));
+    return TTS_HIP_OK;
+}
+
+template <int KS>
+hipError_t launch_lstm(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
+                       const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
+    const size_t lds = (size_t)NB * 256 * KS * sizeof(float);
+    auto kern = lstm_step_kernel<KS>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (er != hipSuccess) return er;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(L.units / 4), dim3(256), lds, s, st, j, L.W, L.b, s0, n0, s1, n1, h_old, h_new,
+                       c_state, B, L.units);
+    return hipGetLastError();
+}
+
+hipError_t lstm_dispatch(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
+                         const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
+    switch ((n0 + n1 + L.units) / 256) {
+        case 7: return launch_lstm<7>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 8: return launch_lstm<8>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 10: return launch_lstm<10>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 11: return launch_lstm<11>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
 
 void tacotron2_free(tts_hip_engine* e) {
     for (void* p : e->taco.allocs) (void)hipFree(p);
@@ -9,10 +616,360 @@ void tacotron2_free(tts_hip_engine* e) {
     e->taco.ready = false;
 }
 
-int tacotron2_finalize(tts_hip_engine* e) { (void)e; return TTS_HIP_OK; }
+int tacotron2_finalize(tts_hip_engine* e) {
+    Tacotron2Dev& tc = e->taco;
+    tacotron2_free(e);
+    auto& al = tc.allocs;
+    int rc;
+    auto get = [&](const char* name) { return find_tensor(e, std::string("tacotron2/") + name); };
+#define NEED(var, name)                                                                     \
+    const HostTensor* var = get(name);                                                      \
+    if (!var) { tacotron2_free(e); return set_err(e, TTS_HIP_ENOTREADY, "missing tensor tacotron2/%s", name); }
+#define TCHK(x) if ((rc = (x))) { tacotron2_free(e); return rc; }
+    NEED(emb, "encoder/embeddings");
+    if (emb->dims != std::vector<int64_t>{148, 512}) { tacotron2_free(e); return set_err(e, TTS_HIP_EINVAL, "embeddings must be [148, 512]"); }
+    TCHK(upload(e, emb->data.data(), emb->numel(), &tc.embeddings, al));
+    for (int i = 0; i < 3; ++i) {
+        const std::string s = std::to_string(i + 1);
+        TCHK(fold_conv_bn(e, "tacotron2/encoder/conv_" + s, "tacotron2/encoder/norm_" + s, 512, 512, &tc.enc_conv[i], al));
+    }
+    {   // BiLSTM: one N = 2048 input projection (forward | backward), recurrent kernels kept in Keras layout
+        NEED(kf, "encoder/bi_lstm/forward/kernel");
+        NEED(kb, "encoder/bi_lstm/backward/kernel");
+        NEED(rf, "encoder/bi_lstm/forward/recurrent_kernel");
+        NEED(rb, "encoder/bi_lstm/backward/recurrent_kernel");
+        NEED(bf, "encoder/bi_lstm/forward/bias");
+        NEED(bb, "encoder/bi_lstm/backward/bias");
+        std::vector<float> Bt((size_t)2048 * 512), bias(2048);
+        for (int n = 0; n < 1024; ++n) {
+            for (int k = 0; k < 512; ++k) {
+                Bt[(size_t)n * 512 + k] = kf->data[(size_t)k * 1024 + n];
+                Bt[(size_t)(1024 + n) * 512 + k] = kb->data[(size_t)k * 1024 + n];
+            }
+            bias[n] = bf->data[n];
+            bias[1024 + n] = bb->data[n];
+        }
+        TCHK(upload(e, Bt.data(), Bt.size(), &tc.bl_in_Bt[0], al));
+        TCHK(upload(e, bias.data(), bias.size(), &tc.bl_in_b[0], al));
+        TCHK(upload(e, rf->data.data(), rf->numel(), &tc.bl_rec[0], al));
+        TCHK(upload(e, rb->data.data(), rb->numel(), &tc.bl_rec[1], al));
+    }
+    NEED(p0, "decoder/prenet/layer_0/kernel");
+    NEED(p1, "decoder/prenet/layer_1/kernel");
+    TCHK(upload_transposed(e, p0, NMEL, PRE, NMEL, &tc.prenet_w0, al));
+    TCHK(upload_transposed(e, p1, PRE, PRE, PRE, &tc.prenet_w1, al));
+    NEED(ak, "decoder/attention_rnn/kernel");
+    NEED(ar, "decoder/attention_rnn/recurrent_kernel");
+    NEED(ab, "decoder/attention_rnn/bias");
+    const int enc = (int)ak->dims[0] - PRE;
+    if (enc != 512 && enc != 768) { tacotron2_free(e); return set_err(e, TTS_HIP_EINVAL, "encoder width %d unsupported (512 or 768)", enc); }
+    tc.enc_dim = enc;
+    tc.spk_dim = enc - 512;
+    NEED(dk, "decoder/decoder_rnn/cell_0/kernel");
+    NEED(dr, "decoder/decoder_rnn/cell_0/recurrent_kernel");
+    NEED(db, "decoder/decoder_rnn/cell_0/bias");
+    {
+        DevBuf s1, s2, s3;
+        auto pack = [&](const HostTensor* k, const HostTensor* r, const HostTensor* b, int kin, LstmDev* L) -> int {
+            const int U = 1024, K = kin + U;
+            HIPCHK(e, s1.ensure(k->numel() * 4));
+            HIPCHK(e, s2.ensure(r->numel() * 4));
+            HIPCHK(e, s3.ensure(b->numel() * 4));
+            HIPCHK(e, hipMemcpyAsync(s1.p, k->data.data(), k->numel() * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(e, hipMemcpyAsync(s2.p, r->data.data(), r->numel() * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(e, hipMemcpyAsync(s3.p, b->data.data(), b->numel() * 4, hipMemcpyHostToDevice, e->stream));
+            int rc2;
+            if ((rc2 = dev_alloc(e, (size_t)4 * U * K, &L->W, al, false))) return rc2;
+            if ((rc2 = dev_alloc(e, (size_t)4 * U, &L->b, al, false))) return rc2;
+            const long long total = 4ll * U * K;
+            hipLaunchKernelGGL(pack_lstm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, s1.f(),
+                               s2.f(), s3.f(), L->W, L->b, kin, U);
+            HIPCHK(e, hipGetLastError());
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            L->units = U;
+            L->kin = kin;
+            return 0;
+        };
+        rc = pack(ak, ar, ab, PRE + enc, &tc.att);
+        if (!rc) rc = pack(dk, dr, db, ARNN + enc, &tc.dec);
+        s1.release();
+        s2.release();
+        s3.release();
+        TCHK(rc);
+    }
+    NEED(qk, "decoder/lsa/query_layer/kernel");       // [1024][128] already "wq_t" layout (k-major)
+    NEED(mk, "decoder/lsa/memory_layer/kernel");      // [enc][128]
+    NEED(vk, "decoder/lsa/value_layer/kernel");       // [128][1]
+    NEED(lc, "decoder/lsa/location_conv/kernel");     // [31][2][32]
+    NEED(ld, "decoder/lsa/location_dense/kernel");    // [32][128]
+    TCHK(upload(e, qk->data.data(), qk->numel(), &tc.query_w, al));
+    TCHK(upload_transposed(e, mk, enc, ATT, enc, &tc.memory_Bt, al));
+    TCHK(upload(e, vk->data.data(), vk->numel(), &tc.value_w, al));
+    {   // fold conv (no bias) and dense (no bias): wloc[(j*2 + c)][a] = sum_f conv[j][c][f] * dense[f][a]
+        std::vector<float> wl((size_t)2 * LOCK * ATT);
+        for (int jc = 0; jc < 2 * LOCK; ++jc)
+            for (int a = 0; a < ATT; ++a) {
+                double s = 0;
+                for (int f = 0; f < 32; ++f) s += (double)lc->data[(size_t)jc * 32 + f] * (double)ld->data[(size_t)f * ATT + a];
+                wl[(size_t)jc * ATT + a] = (float)s;
+            }
+        TCHK(upload(e, wl.data(), wl.size(), &tc.loc_dense, al));
+    }
+    NEED(lk, "decoder/linear_projection/kernel");
+    NEED(lb, "decoder/linear_projection/bias");
+    NEED(gk, "decoder/gate_output/kernel");
+    NEED(gb, "decoder/gate_output/bias");
+    {
+        const int K = DRNN + enc;
+        std::vector<float> pw((size_t)(NMEL + 1) * K), pb(NMEL + 1);
+        for (int o = 0; o < NMEL; ++o) {
+            for (int k = 0; k < K; ++k) pw[(size_t)o * K + k] = lk->data[(size_t)k * NMEL + o];
+            pb[o] = lb->data[o];
+        }
+        for (int k = 0; k < K; ++k) pw[(size_t)NMEL * K + k] = gk->data[k];
+        pb[NMEL] = gb->data[0];
+        TCHK(upload(e, pw.data(), pw.size(), &tc.proj_w, al));
+        TCHK(upload(e, pb.data(), pb.size(), &tc.proj_b, al));
+    }
+    {
+        int cin = NMEL;
+        for (int i = 0; i < 5; ++i) {
+            const int cout = i < 4 ? 512 : NMEL;
+            const std::string s = std::to_string(i + 1);
+            TCHK(fold_conv_bn(e, "tacotron2/postnet/conv_" + s, "tacotron2/postnet/norm_" + s, cin, cout, &tc.post_conv[i], al));
+            cin = cout;
+        }
+    }
+#undef NEED
+#undef TCHK
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    tc.ready = true;
+    return TTS_HIP_OK;
+}
 
-extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t*, int, int, const float*, int, int,
-                                       const float*, int, int, float*, float*, float*, float*, int32_t*, int32_t*,
-                                       int) {
-    return set_err(e, TTS_HIP_ENOTREADY, "tacotron2 kernels not built yet");
+extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                                       int max_len, int early_stop, const float* prenet_masks, int win_len,
+                                       int win_offset, float* mel, float* decoder_output, float* stop_tokens,
+                                       float* attention, int32_t* lengths, int32_t* steps_run, int mem) {
+    if (!e) return TTS_HIP_EINVAL;
+    Tacotron2Dev& tc = e->taco;
+    if (!tc.ready) return set_err(e, TTS_HIP_ENOTREADY, "tacotron2 weights not finalized");
+    if (!tokens || B <= 0 || Tin <= 0 || max_len <= 0 || Tin > 4096 || B > 1024)
+        return set_err(e, TTS_HIP_EINVAL, "tacotron2_infer: bad argument");
+    if (tc.spk_dim > 0 && !speaker) return set_err(e, TTS_HIP_EINVAL, "tacotron2_infer: this model needs a speaker embedding");
+    if (mem != TTS_HIP_MEM_HOST && mem != TTS_HIP_MEM_DEVICE) return set_err(e, TTS_HIP_EINVAL, "bad mem kind %d", mem);
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const int enc = tc.enc_dim;
+    const long long R = (long long)B * Tin;          // encoder rows
+    const long long RD = (long long)B * max_len;     // decoder rows
+
+    // ---------------- workspace arena
+    size_t need = 0;
+    auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
+    sz(R, 4); sz(R, 1); sz(B, 4); sz(R * 512, 4); sz(R * 512, 4); sz(R * 2048, 4); sz(R * enc, 4); sz(R * ATT, 4);
+    sz((size_t)B * tc.spk_dim + 1, 4); sz((size_t)RD * 2 * PRE * (prenet_masks ? 1 : 0) + 1, 4);
+    sz(64, 4);                                                      // DecState
+    sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4);
+    sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
+    sz(RD * NMEL, 4); sz(RD, 4); sz(RD * Tin, 4); sz(RD, 1); sz(RD * NMEL, 4); sz(RD * 512, 4); sz(RD * 512, 4);
+    sz(RD * NMEL, 4); sz(RD * NMEL, 4);
+    need += 4096;
+    HIPCHK(e, tc.ws.ensure(need));
+    Arena A;
+    A.base = (char*)tc.ws.p;
+    A.cap = tc.ws.bytes;
+    int* d_tok = A.take<int>(R);
+    uint8_t* d_mask = A.take<uint8_t>(R);
+    int* d_enc_len = A.take<int>(B);
+    float* d_x0 = A.take<float>(R * 512);
+    float* d_x1 = A.take<float>(R * 512);
+    float* d_xproj = A.take<float>(R * 2048);
+    float* d_memory = A.take<float>(R * enc);
+    float* d_pm = A.take<float>(R * ATT);
+    float* d_spk = A.take<float>((size_t)B * tc.spk_dim + 1);
+    float* d_masks = A.take<float>((size_t)RD * 2 * PRE * (prenet_masks ? 1 : 0) + 1);
+    DecState* d_state = A.take<DecState>(1);
+    float* d_hatt = A.take<float>(2 * B * ARNN);
+    float* d_catt = A.take<float>(B * ARNN);
+    float* d_hdec = A.take<float>(2 * B * DRNN);
+    float* d_cdec = A.take<float>(B * DRNN);
+    float* d_ctx = A.take<float>(B * enc);
+    float* d_p2 = A.take<float>(B * PRE);
+    float* d_frame = A.take<float>(B * NMEL);
+    float* d_energy = A.take<float>(R);
+    float* d_wprev = A.take<float>(R);
+    float* d_wcum = A.take<float>(R);
+    int* d_finished = A.take<int>(B);
+    int* d_lengths = A.take<int>(B);
+    int* d_mainatt = A.take<int>(2 * B);
+    float* d_decout = A.take<float>(RD * NMEL);
+    float* d_stop = A.take<float>(RD);
+    float* d_attn = A.take<float>(RD * Tin);
+    uint8_t* d_dmask = A.take<uint8_t>(RD);
+    float* d_xm = A.take<float>(RD * NMEL);
+    float* d_pa = A.take<float>(RD * 512);
+    float* d_pb = A.take<float>(RD * 512);
+    float* d_post = A.take<float>(RD * NMEL);
+    float* d_mel = A.take<float>(RD * NMEL);
+    if (A.off > A.cap) return set_err(e, TTS_HIP_ENOMEM, "tacotron2 workspace accounting error");
+    const size_t zero_from = (char*)d_state - A.base, zero_to = (char*)d_dmask - A.base;
+
+    // ---------------- inputs
+    const hipMemcpyKind kin = mem == TTS_HIP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    HIPCHK(e, hipMemcpyAsync(d_tok, tokens, R * 4, kin, st));
+    if (tc.spk_dim) HIPCHK(e, hipMemcpyAsync(d_spk, speaker, (size_t)B * tc.spk_dim * 4, kin, st));
+    const float* masks_dev = nullptr;
+    if (prenet_masks) {
+        if (mem == TTS_HIP_MEM_HOST) {
+            HIPCHK(e, hipMemcpyAsync(d_masks, prenet_masks, (size_t)RD * 2 * PRE * 4, kin, st));
+            masks_dev = d_masks;
+        } else {
+            masks_dev = prenet_masks;
+        }
+    }
+    // all recurrent state, loop state, histories and outputs start at zero
+    HIPCHK(e, hipMemsetAsync(A.base + zero_from, 0, zero_to - zero_from, st));
+
+    // ---------------- encoder
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)R), dim3(128), 0, st, d_tok, tc.embeddings, d_x0, d_mask, (int)R, 148);
+    HIPCHK(e, hipGetLastError());
+    hipLaunchKernelGGL(enc_len_kernel, dim3(B), dim3(64), 0, st, d_mask, d_enc_len, Tin);
+    int rc;
+    float* xin = d_x0;
+    float* xout = d_x1;
+    for (int i = 0; i < 3; ++i) {
+        // MaskedConv1D -> BN -> relu; rows at padded tokens are stored as zeros (they are only ever consumed masked)
+        if ((rc = conv_gemm(e, tc.enc_conv[i], xin, 512, xout, (int)R, Tin, d_mask, ACT_RELU, 1))) return rc;
+        std::swap(xin, xout);
+    }
+    {
+        GemmArgs g{};
+        g.M = (int)R;
+        g.N = 2048;
+        g.L = (int)R;
+        g.nseg = 1;
+        g.seg[0] = ASeg{xin, 512, 0, 512, 512};
+        g.Bt = tc.bl_in_Bt[0];
+        g.ldb = 512;
+        g.bias = tc.bl_in_b[0];
+        g.mode = EPI_LINEAR;
+        g.split = 2048;
+        g.out0 = d_xproj;
+        g.ld0 = 2048;
+        HIPCHK(e, gemm_small(g, 1, st));
+    }
+    hipLaunchKernelGGL(bilstm_kernel, dim3(2, B), dim3(1024), 0, st, d_xproj, tc.bl_rec[0], tc.bl_rec[1], d_mask,
+                       d_memory, Tin, enc);
+    HIPCHK(e, hipGetLastError());
+    if (tc.spk_dim) {
+        const long long n = R * tc.spk_dim;
+        hipLaunchKernelGGL(speaker_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_spk, d_mask,
+                           d_memory, Tin, enc, tc.spk_dim, R);
+        HIPCHK(e, hipGetLastError());
+    }
+    {   // processed_memory = memory(masked) @ memory_layer   (location_sensitive_attention.py:96-102)
+        GemmArgs g{};
+        g.M = (int)R;
+        g.N = ATT;
+        g.L = (int)R;
+        g.nseg = 1;
+        g.seg[0] = ASeg{d_memory, enc, 0, enc, enc};
+        g.Bt = tc.memory_Bt;
+        g.ldb = enc;
+        g.mode = EPI_LINEAR;
+        g.split = ATT;
+        g.out0 = d_pm;
+        g.ld0 = ATT;
+        HIPCHK(e, gemm_small(g, 1, st));
+    }
+
+    // ---------------- decoder loop
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
+    HIPCHK(e, hipGetLastError());
+    const size_t sm_lds = (size_t)(Tin + 256) * sizeof(float);
+    auto enqueue_step = [&](int j) -> int {
+        const int par = j & 1;                       // CHUNK is even, so the parity of t equals the parity of j
+        float* hatt_old = d_hatt + (size_t)par * B * ARNN;
+        float* hatt_new = d_hatt + (size_t)(par ^ 1) * B * ARNN;
+        float* hdec_old = d_hdec + (size_t)par * B * DRNN;
+        float* hdec_new = d_hdec + (size_t)(par ^ 1) * B * DRNN;
+        timing_begin(e, 2);
+        hipLaunchKernelGGL(prenet_kernel, dim3(B, 8), dim3(256), 0, st, d_state, j, d_frame, tc.prenet_w0,
+                           tc.prenet_w1, masks_dev, d_p2);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.att, d_p2, PRE, d_ctx, enc, hatt_old, hatt_new, d_catt, B));
+        hipLaunchKernelGGL(energies_kernel, dim3(B, (Tin + 15) / 16), dim3(256), 0, st, d_state, j, hatt_new,
+                           tc.query_w, tc.loc_dense, tc.value_w, d_pm, d_wprev, d_wcum, d_energy, Tin);
+        HIPCHK(e, hipGetLastError());
+        hipLaunchKernelGGL(softmax_ctx_kernel, dim3(B, enc / 128), dim3(256), sm_lds, st, d_state, j, d_energy, d_mask,
+                           d_enc_len, win_len, win_offset, d_mainatt + par * B, d_mainatt + (par ^ 1) * B, d_memory,
+                           d_wprev, d_wcum, d_ctx, d_attn, Tin, enc);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.dec, hatt_new, ARNN, d_ctx, enc, hdec_old, hdec_new, d_cdec, B));
+        hipLaunchKernelGGL(project_kernel, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
+                           tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B, enc);
+        HIPCHK(e, hipGetLastError());
+        timing_end(e);
+        return TTS_HIP_OK;
+    };
+    int host_steps = 0;
+    {
+        // chunks of CHUNK steps; after each chunk the host reads the loop state (one 24-byte copy)
+        DecState h{};
+        const bool use_graph = !e->timing && getenv("TTS_HIP_NO_GRAPH") == nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        if (use_graph) {
+            HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int crc = TTS_HIP_OK;
+            for (int j = 0; j < CHUNK && crc == TTS_HIP_OK; ++j) crc = enqueue_step(j);
+            if (crc == TTS_HIP_OK) hipLaunchKernelGGL(advance_chunk_kernel, dim3(1), dim3(1), 0, st, d_state);
+            hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (crc != TTS_HIP_OK) return crc;
+            HIPCHK(e, ce);
+            HIPCHK(e, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+        }
+        for (int t0 = 0; t0 < max_len; t0 += CHUNK) {
+            if (use_graph) {
+                HIPCHK(e, hipGraphLaunch(gexec, st));
+            } else {
+                for (int j = 0; j < CHUNK; ++j)
+                    if ((rc = enqueue_step(j))) return rc;
+                hipLaunchKernelGGL(advance_chunk_kernel, dim3(1), dim3(1), 0, st, d_state);
+            }
+            HIPCHK(e, hipMemcpyAsync(&h, d_state, sizeof h, hipMemcpyDeviceToHost, st));
+            HIPCHK(e, hipStreamSynchronize(st));
+            host_steps = h.steps_run;
+            if (early_stop && h.n_finished >= B) break;
+        }
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+
+    // ---------------- postnet + residual
+    {
+        const long long n = RD * NMEL;
+        hipLaunchKernelGGL(dec_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_lengths, d_decout,
+                           d_dmask, d_xm, max_len, RD);
+        HIPCHK(e, hipGetLastError());
+        if ((rc = conv_gemm(e, tc.post_conv[0], d_xm, NMEL, d_pa, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[1], d_pa, 512, d_pb, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[2], d_pb, 512, d_pa, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[3], d_pa, 512, d_pb, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[4], d_pb, 512, d_post, (int)RD, max_len, d_dmask, ACT_NONE, 0))) return rc;
+        hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_decout, d_post, d_mel, n);
+        HIPCHK(e, hipGetLastError());
+    }
+
+    // ---------------- outputs
+    const hipMemcpyKind kout = mem == TTS_HIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (mel) HIPCHK(e, hipMemcpyAsync(mel, d_mel, RD * NMEL * 4, kout, st));
+    if (decoder_output) HIPCHK(e, hipMemcpyAsync(decoder_output, d_decout, RD * NMEL * 4, kout, st));
+    if (stop_tokens) HIPCHK(e, hipMemcpyAsync(stop_tokens, d_stop, RD * 4, kout, st));
+    if (attention) HIPCHK(e, hipMemcpyAsync(attention, d_attn, RD * Tin * 4, kout, st));
+    if (lengths) HIPCHK(e, hipMemcpyAsync(lengths, d_lengths, (size_t)B * 4, kout, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (steps_run) *steps_run = host_steps;
+    return TTS_HIP_OK;
 }
