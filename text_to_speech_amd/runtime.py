@@ -1,0 +1,162 @@
+"""Runtime plug-in for the reference's execution seam.
+
+Mirrors /root/reference/utils/keras/runtimes/runtime.py:19-41 (`Runtime` ABC: per-path engine cache, abstract
+`__call__` and `load_engine`) and utils/keras/runtimes/__init__.py:23-45 (`build_runtime` + `_runtimes` registry), so a
+maintainer registers the backend with one line (`_runtimes['hip'] = HipRuntime`) and
+`BaseModel(runtime='hip', ...)` (models/interfaces/base_model.py:139-209) hands every `compiled_infer` call
+(base_model.py:367-375) to `HipRuntime.__call__`.
+
+Call contracts honoured:
+  Tacotron2  models/tts/tacotron2.py:162  compiled_infer(int32[1, Tin] | (tokens, float32[1, E]), max_length=10., **kw)
+             -> object with .mel [B, Tmax, 80], .lengths [B], .attention_weights [B, Tmax, Tin] (+ the other fields of
+             Tacotron2InferenceOutput, tacotron2_arch.py:52-56); unknown kwargs are ignored.
+  WaveGlow   models/tts/waveglow.py:82-132 compiled_infer(float32[B, T, 80], **kw) -> float32[B, T*256];
+             honours z / sigma / deterministic (waveglow_arch.py:244).
+Randomness (the reference samples prenet dropout and z inside the graph) is explicit here: pass `prenet_masks` / `z`,
+or `deterministic=True`, or a `seed` for the documented numpy generator (Bernoulli(0.5) * 2 masks; N(0, 1) noise).
+"""
+from __future__ import annotations
+
+import os
+from abc import ABCMeta, abstractmethod
+
+import numpy as np
+
+from .engine import HipEngine, Tacotron2InferenceOutput, _is_torch_cuda
+
+
+class Runtime(metaclass=ABCMeta):
+    """Same shape as the reference's `Runtime`: engines are cached per `path` in a class-level dict."""
+    _engines = {}
+
+    def __init__(self, path, *, engine=None, reload=False, **kwargs):
+        if engine is None:
+            if path not in self._engines or reload:
+                self._engines[path] = self.load_engine(path, **kwargs)
+            engine = self._engines[path]
+        self.path = path
+        self.engine = engine
+
+    def __repr__(self):
+        return '<{} path={}>'.format(self.__class__.__name__, self.path)
+
+    @abstractmethod
+    def __call__(self, *args, **kwargs):
+        """Performs custom runtime inference."""
+
+    @staticmethod
+    @abstractmethod
+    def load_engine(path, **kwargs):
+        """Loads the custom runtime engine."""
+
+
+class HipRuntime(Runtime):
+    """MI355X engine behind the reference's `compiled_infer`.
+
+    path   : a TTSW weight file (text_to_speech_amd.weights.save_ttsw), or 'synthetic' / 'synthetic:<seed>' for the
+             seeded synthetic weights of SURVEY.md section 8d.
+    model  : 'tacotron2' | 'waveglow' | None (None: dispatch on the input dtype -- integer tokens vs float mels).
+    """
+
+    def __init__(self, path, *, model=None, engine=None, reload=False, device=0, seed=None, **kwargs):
+        super().__init__(path, engine=engine, reload=reload, device=device, **kwargs)
+        self.model = model
+        self._rng = np.random.default_rng(seed)
+        self.max_decoder_steps = int(kwargs.get('max_decoder_steps', 2000))
+
+    @staticmethod
+    def load_engine(path, device=0, speaker_embedding_dim=0, **kwargs):
+        eng = HipEngine(device)
+        if isinstance(path, str) and path.startswith('synthetic'):
+            from . import weights
+            from .config import Tacotron2Config, WaveGlowConfig
+            seed = int(path.split(':', 1)[1]) if ':' in path else 1234
+            eng.load_state(weights.synth_waveglow(WaveGlowConfig(), seed=seed))
+            eng.load_state(weights.synth_tacotron2(Tacotron2Config(speaker_embedding_dim=speaker_embedding_dim),
+                                                   seed=seed))
+        else:
+            if not os.path.exists(path):
+                raise FileNotFoundError(path)
+            eng.load_weights(path)
+        eng.finalize()
+        return eng
+
+    # ------------------------------------------------------------------ dispatch
+    def __call__(self, inputs, *args, **kwargs):
+        model = self.model
+        if model is None:
+            first = inputs[0] if isinstance(inputs, (tuple, list)) else inputs
+            kind = str(getattr(first, 'dtype', ''))
+            model = 'tacotron2' if 'int' in kind else 'waveglow'
+        if model == 'tacotron2':
+            return self.tacotron2_infer(inputs, **kwargs)
+        if model == 'waveglow':
+            return self.waveglow_infer(inputs, *args, **kwargs)
+        raise ValueError(f'unknown model {model!r}')
+
+    # ------------------------------------------------------------------ Tacotron2.infer (tacotron2_arch.py:866-925)
+    def tacotron2_infer(self, inputs, *, max_length=None, early_stopping=True, attn_mask_offset=0.5,
+                        attn_mask_win_len=None, prenet_masks=None, deterministic=False, seed=None, **_ignored):
+        if isinstance(inputs, (tuple, list)):
+            tokens, speaker = inputs[0], (inputs[1] if len(inputs) > 1 else None)
+        else:
+            tokens, speaker = inputs, None
+        dev = _is_torch_cuda(tokens)
+        tok_np = tokens.detach().cpu().numpy() if dev else np.asarray(tokens)
+        if tok_np.ndim == 1:
+            tok_np = tok_np[None]
+            tokens = tokens[None]
+        B = tok_np.shape[0]
+        n_tok = int((tok_np != 0).sum(axis=1).max())
+        if max_length is None:                      # :886-887 (hparam max_decoder_steps)
+            max_len = self.max_decoder_steps
+        elif isinstance(max_length, float):         # :888-892
+            max_len = int(np.float32(n_tok) * np.float32(max_length))
+        else:
+            max_len = int(max_length)
+        max_len = max(1, max_len)
+        if attn_mask_win_len is not None and isinstance(attn_mask_offset, float):   # :894-897
+            attn_mask_offset = int(np.float32(attn_mask_win_len) * np.float32(attn_mask_offset))
+        if prenet_masks is None and not deterministic:
+            rng = self._rng if seed is None else np.random.default_rng(seed)
+            prenet_masks = (rng.random((B, max_len, 2, 256)) >= 0.5).astype(np.float32) * np.float32(2.0)
+            if dev:
+                import torch
+                prenet_masks = torch.from_numpy(prenet_masks).to(tokens.device)
+        return self.engine.tacotron2_infer(
+            tokens if dev else tok_np, speaker=speaker, max_len=max_len, early_stopping=bool(early_stopping),
+            prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0))
+
+    # ------------------------------------------------------------------ WaveGlow.infer (waveglow_arch.py:244-306)
+    def waveglow_infer(self, mel, z=None, sigma=1.0, deterministic=False, seed=None, **_ignored):
+        dev = _is_torch_cuda(mel)
+        if not dev:
+            mel = np.asarray(mel, dtype=np.float32)
+        if mel.ndim == 2:
+            mel = mel[None]
+        B, T = int(mel.shape[0]), int(mel.shape[1])
+        if z is None and not deterministic:
+            if dev:
+                import torch
+                gen = None
+                if seed is not None:
+                    gen = torch.Generator(device=mel.device)
+                    gen.manual_seed(int(seed))
+                z = torch.randn((B, T * 32, 8), dtype=torch.float32, device=mel.device, generator=gen)
+            else:
+                rng = self._rng if seed is None else np.random.default_rng(seed)
+                z = rng.standard_normal((B, T * 32, 8)).astype(np.float32)
+        return self.engine.waveglow_infer(mel, z=z, sigma=float(sigma))
+
+
+_runtimes = {'hip': HipRuntime}
+
+
+def build_runtime(runtime, path, *args, **kwargs):
+    """Same signature and error behaviour as the reference's `build_runtime` (runtimes/__init__.py:23-37)."""
+    if runtime not in _runtimes:
+        raise ValueError('Unsupported runtime !\n  Accepted : {}\n  Got : {}'.format(tuple(_runtimes.keys()), runtime))
+    return _runtimes[runtime](path, *args, **kwargs)
+
+
+__all__ = ['Runtime', 'HipRuntime', 'build_runtime', 'Tacotron2InferenceOutput']
