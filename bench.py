@@ -65,6 +65,39 @@ def cpu_baseline(wg_weights, cfg, frames: int, threads: int):
     }
 
 
+def secondary_metrics(eng, dev, rank):
+    """The other numbers BASELINE.json's metric names (batch 1 WaveGlow; Tacotron2 mel-frames/s at batch 1 and 8),
+    measured after the headline region on the same engine.  Tacotron2: 100-token utterances padded to 128, 800 decoder
+    steps with early stopping off, deterministic prenet, seeded synthetic weights; encoder + postnet included."""
+    import torch
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import Tacotron2Config
+    out = {}
+    mel1 = torch.from_numpy(np.random.default_rng(3).uniform(-11.5, 1.2, (1, FRAMES, 80)).astype(np.float32)).to(dev)
+    z1 = torch.from_numpy(np.random.default_rng(4).standard_normal((1, FRAMES * 32, 8)).astype(np.float32)).to(dev)
+    eng.waveglow_infer(mel1, z=z1)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.waveglow_infer(mel1, z=z1)
+    dt = (time.perf_counter() - t0) / 3
+    out['waveglow_batch1_samples_per_s'] = FRAMES * 256 / dt
+    eng.load_state(weights.synth_tacotron2(Tacotron2Config(), seed=1234))
+    eng.finalize()
+    for B in (1, 8):
+        tok = np.zeros((B, 128), np.int32)
+        tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
+        tok_d = torch.from_numpy(tok).to(dev)
+        eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            eng.tacotron2_infer(tok_d, max_len=FRAMES, early_stopping=False, want_attention=False)
+        dt = (time.perf_counter() - t0) / reps
+        out[f'tacotron2_batch{B}_mel_frames_per_s'] = B * FRAMES / dt
+        out[f'tacotron2_batch{B}_us_per_decoder_step'] = 1e6 * dt / FRAMES
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -74,6 +107,7 @@ def main():
     ap.add_argument('--frames', type=int, default=FRAMES)
     ap.add_argument('--cpu-frames', type=int, default=480, help='mel frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary (untimed-region) metrics')
     args = ap.parse_args()
 
     import torch
@@ -131,6 +165,8 @@ def main():
     assert bool(torch.isfinite(out).all())
 
     avg_us, launches = (0.0, 0) if args.no_kernel_timing else eng.kernel_time_us(KERNEL_WN_IN)
+    eng.kernel_timing(False)
+    extra = secondary_metrics(eng, dev, rank) if (rank == 0 and not args.no_extra) else None
     samples = world * B * T * 256 * args.steps
     result = None
     if rank == 0:
@@ -156,7 +192,7 @@ def main():
                        'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
                        'weights': 'seeded synthetic (rng 1234)'},
             'x_realtime': samples / dt / SAMPLE_RATE,
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'extra': extra,
         }
         print(json.dumps(result), flush=True)
     if distributed:

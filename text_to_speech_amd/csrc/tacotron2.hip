@@ -27,6 +27,8 @@ using namespace ttsgemm;
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int NB = 8;                 // batch rows processed together by the LSTM kernel (zero padded)
 constexpr int PRE = 256, ARNN = 1024, DRNN = 1024, ATT = 128, NMEL = 80, LOCK = 31;
 constexpr int CHUNK = 32;             // decoder steps per hipGraph replay
@@ -142,58 +144,77 @@ __device__ __forceinline__ bool step_done(const DecState* st, int j, int& t) {
 }
 
 // prenet: grid (B, 8).  Every block recomputes layer 1 (80 -> 256) for its row, then its 32 outputs of layer 2.
+// All weight loads are issued before anything else (one memory round trip), the loop state is only needed for the
+// dropout-mask index and the final store.
 __global__ __launch_bounds__(256) void prenet_kernel(const DecState* __restrict__ st, int j,
                                                      const float* __restrict__ frame, const float* __restrict__ w0,
                                                      const float* __restrict__ w1, const float* __restrict__ masks,
                                                      float* __restrict__ p2) {
-    int t;
-    if (step_done(st, j, t)) return;
-    __shared__ float f_s[NMEL];
-    __shared__ float p1_s[PRE];
+    __shared__ __attribute__((aligned(16))) float f_s[NMEL];
+    __shared__ __attribute__((aligned(16))) float p1_s[PRE];
     const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    const int o = part * 32 + (tid >> 3), sub = tid & 7;
+    f32x4 wa[NMEL / 4], wb[8];
+#pragma unroll
+    for (int i = 0; i < NMEL / 4; ++i) wa[i] = *reinterpret_cast<const f32x4*>(w0 + tid * NMEL + i * 4);   // [256][80]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wb[i] = *reinterpret_cast<const f32x4*>(w1 + o * PRE + sub * 32 + i * 4);
     if (tid < NMEL) f_s[tid] = frame[b * NMEL + tid];
+    int t;
+    const bool done = step_done(st, j, t);
+    float m0 = 1.f, m1 = 1.f;
+    if (masks && !done) {
+        const long long base = ((long long)b * st->max_len + t) * 2 * PRE;
+        m0 = masks[base + tid];
+        m1 = masks[base + PRE + o];
+    }
     __syncthreads();
     {
-        const float* w = w0 + tid * NMEL;                       // w0 is out-major [256][80]
         float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < NMEL; ++k) acc = fmaf(f_s[k], w[k], acc);
-        acc = fmaxf(acc, 0.f);
-        if (masks) acc *= masks[(((long long)b * st->max_len + t) * 2 + 0) * PRE + tid];
-        p1_s[tid] = acc;
+#pragma unroll
+        for (int i = 0; i < NMEL / 4; ++i) {
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(f_s + i * 4);
+            acc = fmaf(fv[0], wa[i][0], acc);
+            acc = fmaf(fv[1], wa[i][1], acc);
+            acc = fmaf(fv[2], wa[i][2], acc);
+            acc = fmaf(fv[3], wa[i][3], acc);
+        }
+        p1_s[tid] = fmaxf(acc, 0.f) * m0;
     }
     __syncthreads();
     {   // 32 outputs per block, 8 lanes per output
-        const int o = part * 32 + (tid >> 3), sub = tid & 7;
-        const float* w = w1 + o * PRE + sub * 32;
         float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) acc = fmaf(p1_s[sub * 32 + k], w[k], acc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(p1_s + sub * 32 + i * 4);
+            acc = fmaf(pv[0], wb[i][0], acc);
+            acc = fmaf(pv[1], wb[i][1], acc);
+            acc = fmaf(pv[2], wb[i][2], acc);
+            acc = fmaf(pv[3], wb[i][3], acc);
+        }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
-        if (sub == 0) {
-            acc = fmaxf(acc, 0.f);
-            if (masks) acc *= masks[(((long long)b * st->max_len + t) * 2 + 1) * PRE + o];
-            p2[b * PRE + o] = acc;
-        }
+        if (sub == 0 && !done) p2[b * PRE + o] = fmaxf(acc, 0.f) * m1;
     }
 }
 
 // One LSTM step.  K = 256 * KS inputs = [seg0 | seg1 | seg2(recurrent h)]; block = 4 waves = 4 hidden units; each wave
-// keeps its 4 gate rows (i, f, c, o of one unit) in registers (KS float4 per row per lane), x for NB batch rows is staged
-// in LDS, and the 4 x NB partial sums are reduced with a lane-halving exchange (32 shuffles instead of 192).
-template <int KS>
+// keeps its 4 gate rows (i, f, c, o of one unit) in registers (KS float4 per row per lane), x for NBT batch rows is
+// staged in LDS (all loads of the staging pass in flight at once), and the 4 x NBT partial sums are reduced with a
+// lane-halving exchange (V - 1 + log2(64 / V) shuffles for V = 4 * NBT values instead of 6 V).
+template <int KS, int NBT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restrict__ st, int j,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         const float* __restrict__ s0, int n0,
                                                         const float* __restrict__ s1, int n1,
                                                         const float* __restrict__ h_old, float* __restrict__ h_new,
                                                         float* __restrict__ c_state, int B, int U) {
-    int t;
-    if (step_done(st, j, t)) return;
     constexpr int K = 256 * KS;
-    extern __shared__ __attribute__((aligned(16))) float xs[];      // [NB][K]
+    constexpr int V = 4 * NBT;                                       // partial sums per lane
+    constexpr int NX4 = NBT * (K / 4);                               // float4 of x to stage
+    constexpr int NST = (NX4 + 255) / 256;                           // staging float4 per thread
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // [NBT][K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = blockIdx.x * 4 + wave;
     // weights -> registers (issued first: the longest-latency stream)
@@ -204,42 +225,91 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
 #pragma unroll
         for (int i = 0; i < KS; ++i) w[gt][i] = *reinterpret_cast<const f32x4*>(wrow + (long long)gt * K + i * 256);
 
-    for (int b0 = 0; b0 < B; b0 += NB) {
-        if (b0) __syncthreads();
-        // stage x[b][:] = [s0[b] | s1[b] | h_old[b]] for NB rows (zeros beyond B)
-        for (int idx = tid; idx < NB * (K / 4); idx += 256) {
+    // stage x[b][:] = [s0[b] | s1[b] | h_old[b]] for NBT rows (zeros beyond B): every load of a pass is issued before
+    // any LDS store, and the first pass is issued right behind the weight loads so both streams are in flight together
+    f32x4 sv[NST];
+    auto issue_stage = [&](int b0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = tid + i * 256;
             const int bb = idx / (K / 4), k = (idx % (K / 4)) * 4;
             const int b = b0 + bb;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b < B) {
-                if (k < n0) v = *reinterpret_cast<const f32x4*>(s0 + (long long)b * n0 + k);
-                else if (k < n0 + n1) v = *reinterpret_cast<const f32x4*>(s1 + (long long)b * n1 + (k - n0));
-                else v = *reinterpret_cast<const f32x4*>(h_old + (long long)b * U + (k - n0 - n1));
+            if (idx < NX4 && b < B) {
+                const float* src = k < n0 ? s0 + (long long)b * n0 + k
+                                 : k < n0 + n1 ? s1 + (long long)b * n1 + (k - n0)
+                                               : h_old + (long long)b * U + (k - n0 - n1);
+                v = *reinterpret_cast<const f32x4*>(src);
             }
-            *reinterpret_cast<f32x4*>(xs + bb * K + k) = v;
+            sv[i] = v;
+        }
+    };
+    constexpr int b0 = 0;                       // B <= NBT per launch (the host loops over batch chunks)
+    issue_stage(0);
+    // pin the weights: without this the compiler sinks each weight load next to its first use inside the FMA loop
+    // (serialising HBM round trips) when register pressure is high (NBT = 8)
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(w[gt][i]));
+
+    {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < NX4) *reinterpret_cast<f32x4*>(xs + (idx / (K / 4)) * K + (idx % (K / 4)) * 4) = sv[i];
         }
         __syncthreads();
-        float acc[4 * NB];                                           // index gate * NB + b
+        // Packed accumulation: each (gate, row) sum is kept as an (even-k, odd-k) pair so that one v_pk_fma_f32 takes two
+        // adjacent registers of the x float4 and of the weight float4.  x is read from LDS in groups of 4 float4, one
+        // group ahead of the FMAs that consume it (explicit double buffer; the compiler barrier keeps it from hoisting
+        // every LDS read to the top, which spilled at NBT = 8).
+        f32x2 acc2[V];
 #pragma unroll
-        for (int i = 0; i < 4 * NB; ++i) acc[i] = 0.f;
+        for (int i = 0; i < V; ++i) acc2[i] = f32x2{0.f, 0.f};
+        constexpr int P = KS * NBT, GSZ = 4, G = (P + GSZ - 1) / GSZ;
+        f32x4 xbuf[2][GSZ];
+        const float* xl = xs + lane * 4;
 #pragma unroll
-        for (int i = 0; i < KS; ++i)
+        for (int q = 0; q < GSZ; ++q)
+            if (q < P) xbuf[0][q] = *reinterpret_cast<const f32x4*>(xl + (q % NBT) * K + (q / NBT) * 256);
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + bb * K + i * 256 + lane * 4);
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) {
 #pragma unroll
-                for (int gt = 0; gt < 4; ++gt) {
-                    float a = acc[gt * NB + bb];
-                    a = fmaf(xv[0], w[gt][i][0], a);
-                    a = fmaf(xv[1], w[gt][i][1], a);
-                    a = fmaf(xv[2], w[gt][i][2], a);
-                    a = fmaf(xv[3], w[gt][i][3], a);
-                    acc[gt * NB + bb] = a;
+                for (int q = 0; q < GSZ; ++q) {
+                    const int pp = (g + 1) * GSZ + q;
+                    if (pp < P) xbuf[(g + 1) & 1][q] = *reinterpret_cast<const f32x4*>(xl + (pp % NBT) * K + (pp / NBT) * 256);
                 }
             }
-        // lane-halving reduction: after masks 32,16,8,4,2 lane l holds output index (l >> 1) & 31, then mask 1
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int half = 16, m = 32; half >= 1; half >>= 1, m >>= 1) {
+            for (int q = 0; q < GSZ; ++q) {
+                const int pp = g * GSZ + q;
+                if (pp < P) {
+                    const int i = pp / NBT, bb = pp % NBT;
+                    const f32x4 xv = xbuf[g & 1][q];
+                    const f32x2 xlo = {xv[0], xv[1]}, xhi = {xv[2], xv[3]};
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) {
+                        const f32x2 wlo = {w[gt][i][0], w[gt][i][1]}, whi = {w[gt][i][2], w[gt][i][3]};
+                        f32x2 a = acc2[gt * NBT + bb];
+                        a = __builtin_elementwise_fma(xlo, wlo, a);
+                        a = __builtin_elementwise_fma(xhi, whi, a);
+                        acc2[gt * NBT + bb] = a;
+                    }
+                }
+            }
+        }
+        float acc[V];                                                // index gate * NBT + b
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = acc2[i][0] + acc2[i][1];
+        // lane-halving reduction over masks 32, 16, ...: afterwards lane l holds output index l >> SH, summed over the
+        // lanes that share its top bits; the remaining low-bit masks are a plain butterfly.
+        constexpr int LOGV = NBT == 1 ? 2 : NBT == 2 ? 3 : NBT == 4 ? 4 : 5;
+        constexpr int SH = 6 - LOGV;
+#pragma unroll
+        for (int half = V / 2, m = 32; half >= 1; half >>= 1, m >>= 1) {
             const bool hi = (lane & m) != 0;
 #pragma unroll
             for (int i = 0; i < half; ++i) {
@@ -248,15 +318,19 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
                 acc[i] = keep + __shfl_xor(send, m, 64);
             }
         }
-        float v = acc[0] + __shfl_xor(acc[0], 1, 64);
-        // lane 2*(gate*NB + bb) holds gate pre-activation (without bias) of (gate, bb): gather the 4 gates per bb
-        const int src_b = (lane >> 1) & (NB - 1);
-        const float gi = __shfl(v, 2 * (0 * NB + src_b), 64);
-        const float gf = __shfl(v, 2 * (1 * NB + src_b), 64);
-        const float gg = __shfl(v, 2 * (2 * NB + src_b), 64);
-        const float go = __shfl(v, 2 * (3 * NB + src_b), 64);
-        if (lane < 2 * NB && (lane & 1) == 0) {
-            const int b = b0 + (lane >> 1);
+        float v = acc[0];
+#pragma unroll
+        for (int m = (1 << SH) >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        // lane (gate * NBT + bb) << SH holds the gate pre-activation (without bias): gather the 4 gates per bb
+        const int src_b = (lane >> SH) & (NBT - 1);
+        const float gi = __shfl(v, (0 * NBT + src_b) << SH, 64);
+        const float gf = __shfl(v, (1 * NBT + src_b) << SH, 64);
+        const float gg = __shfl(v, (2 * NBT + src_b) << SH, 64);
+        const float go = __shfl(v, (3 * NBT + src_b) << SH, 64);
+        int t;
+        const bool done = step_done(st, j, t);      // only the final stores depend on the loop state
+        if (!done && lane < (NBT << SH) && (lane & ((1 << SH) - 1)) == 0) {
+            const int b = b0 + (lane >> SH);
             if (b < B) {
                 const float ig = sigmoid_exact(gi + bp[4 * u + 0]);
                 const float fg = sigmoid_exact(gf + bp[4 * u + 1]);
@@ -270,24 +344,81 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
     }
 }
 
-// energies: grid (B, ceil(Tin / 16)).  q = h_att @ Wq is recomputed per block (Wq^T is L2 resident); the location conv
-// (2 -> 32, k 31) and dense (32 -> 128) are folded at load time into one [62][128] map (no nonlinearity in between).
+// q[b][a] = sum_k h_att[b][k] * Wq[k][a]: one block per 2 attention dims, one float4 of k per thread, block reduction.
+__global__ __launch_bounds__(256) void query_kernel(const DecState* __restrict__ st, int j,
+                                                    const float* __restrict__ h_att, const float* __restrict__ wq_a,
+                                                    float* __restrict__ q, int B) {
+    __shared__ float red_s[2][4][NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a0 = blockIdx.x * 2;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wq_a + (long long)a0 * ARNN + tid * 4);        // wq_a is [128][1024]
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wq_a + (long long)(a0 + 1) * ARNN + tid * 4);
+    for (int b0 = 0; b0 < B; b0 += NB) {
+        f32x4 hv[NB];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            hv[bb] = b0 + bb < B ? *reinterpret_cast<const f32x4*>(h_att + (long long)(b0 + bb) * ARNN + tid * 4) : zero;
+        }
+        float acc[2 * NB];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            acc[bb] = hv[bb][0] * w0[0] + hv[bb][1] * w0[1] + hv[bb][2] * w0[2] + hv[bb][3] * w0[3];
+            acc[NB + bb] = hv[bb][0] * w1[0] + hv[bb][1] * w1[1] + hv[bb][2] * w1[2] + hv[bb][3] * w1[3];
+        }
+        // 16 values: halving over masks 32..4, then masks 2, 1
+#pragma unroll
+        for (int half = NB, m = 32; half >= 1; half >>= 1, m >>= 1) {
+            const bool hi = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const float send = hi ? acc[i] : acc[i + half];
+                const float keep = hi ? acc[i + half] : acc[i];
+                acc[i] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        float v = acc[0];
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        if ((lane & 3) == 0) red_s[(lane >> 2) >> 3][wave][(lane >> 2) & 7] = v;     // idx = lane >> 2 = a_local * NB + bb
+        __syncthreads();
+        int t;
+        if (tid < 2 * NB && !step_done(st, j, t)) {
+            const int al = tid >> 3, bb = tid & 7;
+            if (b0 + bb < B)
+                q[(long long)(b0 + bb) * ATT + a0 + al] = (red_s[al][0][bb] + red_s[al][1][bb]) + (red_s[al][2][bb] + red_s[al][3][bb]);
+        }
+        __syncthreads();
+    }
+}
+
+// energies: grid (B, ceil(Tin / 16)).  The location conv (2 -> 32, k 31) and dense (32 -> 128) are folded at load time
+// into one [62][128] map (no nonlinearity in between); e[t] = sum_a v[a] * tanh(q[a] + pm[t][a] + loc[t][a]).
 __global__ __launch_bounds__(256) void energies_kernel(const DecState* __restrict__ st, int j,
-                                                       const float* __restrict__ h_att, const float* __restrict__ wq_t,
-                                                       const float* __restrict__ wloc, const float* __restrict__ v_w,
-                                                       const float* __restrict__ pm, const float* __restrict__ w_prev,
+                                                       const float* __restrict__ q, const float* __restrict__ wloc,
+                                                       const float* __restrict__ v_w, const float* __restrict__ pm,
+                                                       const float* __restrict__ w_prev,
                                                        const float* __restrict__ w_cum, float* __restrict__ energies,
                                                        int Tin) {
-    int t;
-    if (step_done(st, j, t)) return;
-    __shared__ float h_s[ARNN];
-    __shared__ float q_s[2][ATT];
     __shared__ float cat_s[2][16 + LOCK - 1];
     __shared__ __attribute__((aligned(16))) float wl_s[2 * LOCK * ATT];
     const int b = blockIdx.x, tc = blockIdx.y, tid = threadIdx.x;
     const int tbase = tc * 16;
-    for (int k = tid; k < ARNN; k += 256) h_s[k] = h_att[(long long)b * ARNN + k];
-    for (int i = tid; i < 2 * LOCK * ATT; i += 256) wl_s[i] = wloc[i];
+    {
+        constexpr int N4 = 2 * LOCK * ATT / 4;                     // 1984 float4
+        f32x4 tmp[(N4 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i) {
+            const int idx = tid + i * 256;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            tmp[i] = idx < N4 ? *reinterpret_cast<const f32x4*>(wloc + idx * 4) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < N4) *reinterpret_cast<f32x4*>(wl_s + idx * 4) = tmp[i];
+        }
+    }
     if (tid < 2 * (16 + LOCK - 1)) {
         const int c = tid / (16 + LOCK - 1), p = tid % (16 + LOCK - 1);
         const int tt = tbase + p - (LOCK / 2);
@@ -295,22 +426,23 @@ __global__ __launch_bounds__(256) void energies_kernel(const DecState* __restric
         if (tt >= 0 && tt < Tin) v = (c == 0 ? w_prev : w_cum)[(long long)b * Tin + tt];
         cat_s[c][p] = v;
     }
-    __syncthreads();
-    {   // q[a]: two K halves per output, wq_t is [1024][128] so consecutive threads read consecutive floats
-        const int a = tid & (ATT - 1), half = tid >> 7;
-        const float* w = wq_t + (long long)half * 512 * ATT + a;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 512; ++k) acc = fmaf(h_s[half * 512 + k], w[(long long)k * ATT], acc);
-        q_s[half][a] = acc;
-    }
-    __syncthreads();
     // thread (tl, al): position tbase + tl, attention dims al*8 .. al*8+7
     const int tl = tid >> 4, al = tid & 15;
     const int tt = tbase + tl;
+    const bool tok = tt < Tin;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* pmr = pm + ((long long)b * Tin + (tok ? tt : 0)) * ATT + al * 8;
+    const f32x4 pm0 = tok ? *reinterpret_cast<const f32x4*>(pmr) : zero4;
+    const f32x4 pm1 = tok ? *reinterpret_cast<const f32x4*>(pmr + 4) : zero4;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + (long long)b * ATT + al * 8);
+    const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + (long long)b * ATT + al * 8 + 4);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(v_w + al * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(v_w + al * 8 + 4);
+    __syncthreads();
     float loc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) loc[i] = 0.f;
+#pragma unroll 4
     for (int jj = 0; jj < LOCK; ++jj)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -324,24 +456,27 @@ __global__ __launch_bounds__(256) void energies_kernel(const DecState* __restric
             }
         }
     float e = 0.f;
-    if (tt < Tin) {
-        const float* pmr = pm + ((long long)b * Tin + tt) * ATT + al * 8;
+    if (tok) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int a = al * 8 + i;
-            const float qv = q_s[0][a] + q_s[1][a];
-            e = fmaf(v_w[a], tanhf(qv + pmr[i] + loc[i]), e);
+        for (int i = 0; i < 4; ++i) {
+            e = fmaf(v0[i], tanhf(q0[i] + pm0[i] + loc[i]), e);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            e = fmaf(v1[i], tanhf(q1[i] + pm1[i] + loc[4 + i]), e);
         }
     }
     e += __shfl_xor(e, 1, 64);
     e += __shfl_xor(e, 2, 64);
     e += __shfl_xor(e, 4, 64);
     e += __shfl_xor(e, 8, 64);
-    if (al == 0 && tt < Tin) energies[(long long)b * Tin + tt] = e;
+    int t;
+    if (al == 0 && tok && !step_done(st, j, t)) energies[(long long)b * Tin + tt] = e;
 }
 
-// softmax + context: grid (B, enc / 128).  Each block redoes the (cheap) masked softmax over Tin, then its 128 context
-// columns; block y == 0 also updates w_prev / w_cum, the alignment history and main_attention (argmax).
+// softmax + context: grid (B, enc / 32).  Each block redoes the (cheap) masked softmax over Tin, then 32 context columns
+// (8 interleaved slices of Tin per column, loads unrolled); block y == 0 also updates w_prev / w_cum, the alignment
+// history and main_attention (argmax, first index on ties).
 __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __restrict__ st, int j,
                                                           const float* __restrict__ energies,
                                                           const uint8_t* __restrict__ mask,
@@ -352,17 +487,17 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
                                                           float* __restrict__ ctx, float* __restrict__ attn_hist,
                                                           int Tin, int enc) {
     int t;
-    if (step_done(st, j, t)) return;
-    extern __shared__ float sm[];                 // [Tin] weights + 2*128 partials
+    const bool done = step_done(st, j, t);        // consulted only before the stores below
+    extern __shared__ float sm[];                 // [Tin] weights
     float* w_s = sm;
-    float* part = sm + Tin;
+    __shared__ float part[8][32];
     __shared__ float red_s[8];
     __shared__ int redi_s[4];
     const int b = blockIdx.x, ec = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // attention window (tacotron2_arch.py:630-638)
     int lo = 0, hi = Tin;
     if (win_len > 0) {
-        int center = max(main_att_old[b], win_off);      // previous step's argmax (ping-pong: other blocks write the new one)
+        int center = max(main_att_old[b], win_off);      // previous step's argmax (ping-pong: block 0 writes the new one)
         center = min(center, enc_len[b] - win_len + win_off);
         lo = center - win_off;
         hi = center - win_off + win_len;          // inclusive upper bound
@@ -391,18 +526,22 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
     sum = (red_s[4] + red_s[5]) + (red_s[6] + red_s[7]);
     for (int tt = tid; tt < Tin; tt += 256) w_s[tt] = w_s[tt] / sum;
     __syncthreads();
-    // context columns: 128 per block, two halves of Tin per column
     {
-        const int e = ec * 128 + (tid & 127), half = tid >> 7;
-        const int t_lo = half * ((Tin + 1) / 2), t_hi = half ? Tin : (Tin + 1) / 2;
-        const float* mem = memory + (long long)b * Tin * enc + e;
+        const int col = tid & 31, ts = tid >> 5;
+        const float* mem = memory + (long long)b * Tin * enc + ec * 32 + col;
         float acc = 0.f;
-        for (int tt = t_lo; tt < t_hi; ++tt) acc = fmaf(w_s[tt], mem[(long long)tt * enc], acc);
-        part[tid] = acc;
+#pragma unroll 16
+        for (int tt = ts; tt < Tin; tt += 8) acc = fmaf(w_s[tt], mem[(long long)tt * enc], acc);
+        part[ts][col] = acc;
     }
     __syncthreads();
-    if (tid < 128) ctx[(long long)b * enc + ec * 128 + tid] = part[tid] + part[128 + tid];
-    if (ec == 0) {
+    if (tid < 32 && !done) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += part[k][tid];
+        ctx[(long long)b * enc + ec * 32 + tid] = v;
+    }
+    if (ec == 0 && !done) {
         float best = -1.f;
         int besti = 0x7fffffff;
         for (int tt = tid; tt < Tin; tt += 256) {
@@ -428,34 +567,60 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
 }
 
 // projection + stop token + bookkeeping.  grid = 21 blocks x 4 waves = 84 waves >= 81 outputs; wave `o` computes
-// output column o (0..79 mel, 80 gate) for every batch row from cell_out = [h_dec | ctx].
+// output column o (0..79 mel, 80 gate) for every batch row from cell_out = [h_dec | ctx]: its weight row stays in
+// registers, the x loads of NB rows are all in flight together, and the NB sums use the lane-halving reduction.
+template <int KP>
 __global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st, int j, const float* __restrict__ h_dec,
                                                       const float* __restrict__ ctx, const float* __restrict__ pw,
                                                       const float* __restrict__ pb, float* __restrict__ frame,
                                                       float* __restrict__ dec_out, float* __restrict__ stop_out,
-                                                      int* __restrict__ finished, int* __restrict__ lengths, int B,
-                                                      int enc) {
-    int t;
-    if (step_done(st, j, t)) return;
+                                                      int* __restrict__ finished, int* __restrict__ lengths, int B) {
+    constexpr int K = 256 * KP, enc = K - DRNN;
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o > NMEL) return;
-    const int K = DRNN + enc;
-    const float* w = pw + (long long)o * K;
-    for (int b = 0; b < B; ++b) {
-        float acc = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
-            const f32x4 xv = k < DRNN ? *reinterpret_cast<const f32x4*>(h_dec + (long long)b * DRNN + k)
-                                      : *reinterpret_cast<const f32x4*>(ctx + (long long)b * enc + (k - DRNN));
-            acc = fmaf(xv[0], wv[0], acc);
-            acc = fmaf(xv[1], wv[1], acc);
-            acc = fmaf(xv[2], wv[2], acc);
-            acc = fmaf(xv[3], wv[3], acc);
+    f32x4 w[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) w[i] = *reinterpret_cast<const f32x4*>(pw + (long long)o * K + i * 256 + lane * 4);
+    const float bias = pb[o];
+    for (int b0 = 0; b0 < B; b0 += NB) {
+        float acc[NB];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const int b = b0 + bb;
+            float a = 0.f;
+            if (b < B) {
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    const int k = i * 256 + lane * 4;
+                    const f32x4 xv = k < DRNN ? *reinterpret_cast<const f32x4*>(h_dec + (long long)b * DRNN + k)
+                                              : *reinterpret_cast<const f32x4*>(ctx + (long long)b * enc + (k - DRNN));
+                    a = fmaf(xv[0], w[i][0], a);
+                    a = fmaf(xv[1], w[i][1], a);
+                    a = fmaf(xv[2], w[i][2], a);
+                    a = fmaf(xv[3], w[i][3], a);
+                }
+            }
+            acc[bb] = a;
         }
-        for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
-        if (lane == 0) {
-            const float v = acc + pb[o];
+#pragma unroll
+        for (int half = NB / 2, m = 32; half >= 1; half >>= 1, m >>= 1) {
+            const bool hi = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const float send = hi ? acc[i] : acc[i + half];
+                const float keep = hi ? acc[i + half] : acc[i];
+                acc[i] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        float v = acc[0];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        const int b = b0 + (lane >> 3);                      // lane l holds batch row l >> 3 of this chunk
+        int t;
+        if ((lane & 7) == 0 && b < B && !step_done(st, j, t)) {
+            v += bias;
             if (o < NMEL) {
                 frame[b * NMEL + o] = v;
                 dec_out[((long long)b * st->max_len + t) * NMEL + o] = v;
@@ -579,11 +744,11 @@ int conv_gemm(tts_hip_engine* e, const ConvBnDev& cv, const float* x, int ldx, f
     return TTS_HIP_OK;
 }
 
-template <int KS>
+template <int KS, int NBT>
 hipError_t launch_lstm(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
                        const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
-    const size_t lds = (size_t)NB * 256 * KS * sizeof(float);
-    auto kern = lstm_step_kernel<KS>;
+    const size_t lds = (size_t)NBT * 256 * KS * sizeof(float);
+    auto kern = lstm_step_kernel<KS, NBT>;
     static bool attr = false;
     if (!attr) {
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -595,13 +760,34 @@ hipError_t launch_lstm(hipStream_t s, const DecState* st, int j, const LstmDev& 
     return hipGetLastError();
 }
 
+template <int KS>
+hipError_t lstm_by_batch(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
+                         const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
+    // one launch per chunk of <= 8 batch rows (B > 8 re-streams the weights from L2 / Infinity Cache per chunk)
+    for (int b0 = 0; b0 < B; b0 += NB) {
+        const int nb = std::min(NB, B - b0);
+        const float* a0 = s0 + (size_t)b0 * n0;
+        const float* a1 = s1 + (size_t)b0 * n1;
+        const float* ho = h_old + (size_t)b0 * L.units;
+        float* hn = h_new + (size_t)b0 * L.units;
+        float* cs = c_state + (size_t)b0 * L.units;
+        hipError_t er;
+        if (nb == 1) er = launch_lstm<KS, 1>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        else if (nb == 2) er = launch_lstm<KS, 2>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        else if (nb <= 4) er = launch_lstm<KS, 4>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        else er = launch_lstm<KS, 8>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        if (er != hipSuccess) return er;
+    }
+    return hipSuccess;
+}
+
 hipError_t lstm_dispatch(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
                          const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
     switch ((n0 + n1 + L.units) / 256) {
-        case 7: return launch_lstm<7>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
-        case 8: return launch_lstm<8>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
-        case 10: return launch_lstm<10>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
-        case 11: return launch_lstm<11>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 7: return lstm_by_batch<7>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 8: return lstm_by_batch<8>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 10: return lstm_by_batch<10>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 11: return lstm_by_batch<11>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
         default: return hipErrorInvalidValue;
     }
 }
@@ -697,12 +883,12 @@ int tacotron2_finalize(tts_hip_engine* e) {
         s3.release();
         TCHK(rc);
     }
-    NEED(qk, "decoder/lsa/query_layer/kernel");       // [1024][128] already "wq_t" layout (k-major)
+    NEED(qk, "decoder/lsa/query_layer/kernel");       // [1024][128]
     NEED(mk, "decoder/lsa/memory_layer/kernel");      // [enc][128]
     NEED(vk, "decoder/lsa/value_layer/kernel");       // [128][1]
     NEED(lc, "decoder/lsa/location_conv/kernel");     // [31][2][32]
     NEED(ld, "decoder/lsa/location_dense/kernel");    // [32][128]
-    TCHK(upload(e, qk->data.data(), qk->numel(), &tc.query_w, al));
+    TCHK(upload_transposed(e, qk, ARNN, ATT, ARNN, &tc.query_w, al));      // [128][1024]: one attention dim per row
     TCHK(upload_transposed(e, mk, enc, ATT, enc, &tc.memory_Bt, al));
     TCHK(upload(e, vk->data.data(), vk->numel(), &tc.value_w, al));
     {   // fold conv (no bias) and dense (no bias): wloc[(j*2 + c)][a] = sum_f conv[j][c][f] * dense[f][a]
@@ -770,7 +956,7 @@ extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens,
     sz(R, 4); sz(R, 1); sz(B, 4); sz(R * 512, 4); sz(R * 512, 4); sz(R * 2048, 4); sz(R * enc, 4); sz(R * ATT, 4);
     sz((size_t)B * tc.spk_dim + 1, 4); sz((size_t)RD * 2 * PRE * (prenet_masks ? 1 : 0) + 1, 4);
     sz(64, 4);                                                      // DecState
-    sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4);
+    sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4); sz(B * ATT, 4);
     sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
     sz(RD * NMEL, 4); sz(RD, 4); sz(RD * Tin, 4); sz(RD, 1); sz(RD * NMEL, 4); sz(RD * 512, 4); sz(RD * 512, 4);
     sz(RD * NMEL, 4); sz(RD * NMEL, 4);
@@ -796,6 +982,7 @@ extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens,
     float* d_cdec = A.take<float>(B * DRNN);
     float* d_ctx = A.take<float>(B * enc);
     float* d_p2 = A.take<float>(B * PRE);
+    float* d_q = A.take<float>(B * ATT);
     float* d_frame = A.take<float>(B * NMEL);
     float* d_energy = A.take<float>(R);
     float* d_wprev = A.take<float>(R);
@@ -887,7 +1074,7 @@ extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens,
     // ---------------- decoder loop
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
     HIPCHK(e, hipGetLastError());
-    const size_t sm_lds = (size_t)(Tin + 256) * sizeof(float);
+    const size_t sm_lds = (size_t)Tin * sizeof(float);
     auto enqueue_step = [&](int j) -> int {
         const int par = j & 1;                       // CHUNK is even, so the parity of t equals the parity of j
         float* hatt_old = d_hatt + (size_t)par * B * ARNN;
@@ -899,16 +1086,22 @@ extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens,
                            tc.prenet_w1, masks_dev, d_p2);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, lstm_dispatch(st, d_state, j, tc.att, d_p2, PRE, d_ctx, enc, hatt_old, hatt_new, d_catt, B));
-        hipLaunchKernelGGL(energies_kernel, dim3(B, (Tin + 15) / 16), dim3(256), 0, st, d_state, j, hatt_new,
-                           tc.query_w, tc.loc_dense, tc.value_w, d_pm, d_wprev, d_wcum, d_energy, Tin);
+        hipLaunchKernelGGL(query_kernel, dim3(ATT / 2), dim3(256), 0, st, d_state, j, hatt_new, tc.query_w, d_q, B);
         HIPCHK(e, hipGetLastError());
-        hipLaunchKernelGGL(softmax_ctx_kernel, dim3(B, enc / 128), dim3(256), sm_lds, st, d_state, j, d_energy, d_mask,
+        hipLaunchKernelGGL(energies_kernel, dim3(B, (Tin + 15) / 16), dim3(256), 0, st, d_state, j, d_q, tc.loc_dense,
+                           tc.value_w, d_pm, d_wprev, d_wcum, d_energy, Tin);
+        HIPCHK(e, hipGetLastError());
+        hipLaunchKernelGGL(softmax_ctx_kernel, dim3(B, enc / 32), dim3(256), sm_lds, st, d_state, j, d_energy, d_mask,
                            d_enc_len, win_len, win_offset, d_mainatt + par * B, d_mainatt + (par ^ 1) * B, d_memory,
                            d_wprev, d_wcum, d_ctx, d_attn, Tin, enc);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, lstm_dispatch(st, d_state, j, tc.dec, hatt_new, ARNN, d_ctx, enc, hdec_old, hdec_new, d_cdec, B));
-        hipLaunchKernelGGL(project_kernel, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
-                           tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B, enc);
+        if (enc == 512)
+            hipLaunchKernelGGL(project_kernel<6>, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
+                               tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B);
+        else
+            hipLaunchKernelGGL(project_kernel<7>, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
+                               tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B);
         HIPCHK(e, hipGetLastError());
         timing_end(e);
         return TTS_HIP_OK;
