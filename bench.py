@@ -38,6 +38,21 @@ def wn_in_layer_flops(M: int) -> float:
     return 2.0 * M * (3 * 512 + 640) * 1024
 
 
+def pmc_traffic_bytes(B, T):
+    """HBM bytes per launch of the WN in-layer GEMM from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this command, summarised in profiles/): 2 * FETCH_SIZE + WRITE_SIZE KB (gfx950 reports half the
+    bytes of 16-B/lane reads -- MI355X_MICROARCH.md HBM section).  Only valid for the profiled workload (B 8, T 800)."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic_latest.json')
+    if (B, T) != (BATCH, FRAMES) or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        k = d['wn_in_layer']
+        return (2.0 * k['FETCH_SIZE_KB_mean'] + k['WRITE_SIZE_KB_mean']) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(wg_weights, cfg, frames: int, threads: int):
     """Times the numpy oracle on `frames` mel frames, batch 1 (oracle = checker; here only as the reported CPU leg)."""
     from oracle import waveglow_ref
@@ -175,7 +190,9 @@ def main():
         if launches:
             achieved = wn_in_layer_flops(M) / (avg_us * 1e-6) / 1e12
             roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                        'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic_bytes(B, T),
+                        'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
+                        'algorithmic_bytes': (M * (512 + 640 + 512) + 1024 * 2176) * 4.0,
                         'kernel': 'gemm_f32_kernel<4,1,2,4> (WN in-layer implicit GEMM)', 'launches_timed': launches,
                         'avg_launch_us': avg_us}
         cpu = None
