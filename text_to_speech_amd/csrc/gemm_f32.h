@@ -82,7 +82,9 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned by
 // WR x WC waves, each owning RT x CT MFMA tiles of 32x32.  TAG only separates instantiations by name so that
 // profiles list the WaveGlow in-layer GEMM, the res/skip GEMM and the generic uses as different kernels.
 // BK = K extent of one LDS stage (16 or 32); OCC = blocks per CU the register/LDS budget is sized for.
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG>
+// NI > 0: the first NI segments (same k / kpad) are interleaved chunk-wise in K -- tile order (kc, s) -- so that the
+// shifted re-reads of one operand (the three conv taps of x) are one K step apart and hit L2 instead of HBM.
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
@@ -173,42 +175,51 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     for (int p = 0; p < PB; ++p)
         b_off[p] = (n0 + p * RPP + lrow < g.N) ? (unsigned)(((p * RPP + lrow) * (int)g.ldb + c4) * 4) : OOB;
 
-    int nT = 0;
-    for (int s = 0; s < g.nseg; ++s) nT += g.seg[s].kpad / BK;
-
-    // tile iterator (wave-uniform): current segment parameters live in registers, refreshed only at a crossing
-    int s_cur = 0, kc_cur = 0, kglob = 0;
+    // tile iterator (wave-uniform) over the sequential segments [NI, nseg): current segment parameters live in
+    // registers, refreshed only at a crossing
+    int s_cur = NI, kc_cur = 0, kglob = 0;
     int seg_k = 0, seg_kpad = 0;
     __amdgpu_buffer_rsrc_t rsA;
     unsigned a_off[PA];
+    auto seg_rsrc = [&](const ASeg& sg) {
+        return make_rsrc(sg.ptr + z * g.strideAz + ((long long)m0 + sg.shift) * sg.ld);
+    };
+    auto seg_offsets = [&](const ASeg& sg, unsigned (&off)[PA]) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int l2 = a_l[p] + sg.shift;
+            off[p] = (l2 >= 0 && l2 < g.L) ? (unsigned)(((p * RPP + lrow) * (int)sg.ld + c4) * 4) : OOB;
+        }
+    };
     auto enter_segment = [&]() {
         const ASeg sg = g.seg[s_cur];
         seg_k = sg.k;
         seg_kpad = sg.kpad;
-        rsA = make_rsrc(sg.ptr + z * g.strideAz + ((long long)m0 + sg.shift) * sg.ld);
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int l2 = a_l[p] + sg.shift;
-            a_off[p] = (l2 >= 0 && l2 < g.L) ? (unsigned)(((p * RPP + lrow) * (int)sg.ld + c4) * 4) : OOB;
-        }
+        rsA = seg_rsrc(sg);
+        seg_offsets(sg, a_off);
     };
 
-    f32x4 ra[PA], rb[PB];
-    auto load_tile = [&]() {
-        const unsigned kb = (unsigned)(kc_cur * BK * 4);
-        const bool kok = kc_cur * BK + c4 < seg_k;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) ra[p] = buf_load4(rsA, kok ? a_off[p] + kb : OOB);
+    // two register stages: tile t+1 waits in one while tile t+2 is being fetched into the other (prefetch distance of
+    // two K steps: an HBM / Infinity-Cache miss has ~2 K steps to land before its ds_write needs it)
+    f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+    auto load_B = [&](f32x4 (&rb)[PB]) {
         const unsigned kg = (unsigned)(kglob * 4);
 #pragma unroll
         for (int p = 0; p < PB; ++p) rb[p] = buf_load4(rsB, b_off[p] + kg);
         kglob += BK;
+    };
+    auto load_seq = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {       // next tile of the sequential segments
+        const unsigned kb = (unsigned)(kc_cur * BK * 4);
+        const bool kok = kc_cur * BK + c4 < seg_k;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) ra[p] = buf_load4(rsA, kok ? a_off[p] + kb : OOB);
+        load_B(rb);
         if (++kc_cur * BK >= seg_kpad) {
             kc_cur = 0;
             if (++s_cur < g.nseg) enter_segment();
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[PA], const f32x4 (&rb)[PB]) {
         float* a = As + buf * BM * LDSK;
         float* b = Bs + buf * BN * LDSK;
 #pragma unroll
@@ -233,22 +244,80 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
     };
 
-    enter_segment();
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-    // Steady state: the next tile's global loads are issued first, three quarters of the MFMAs run on the current LDS
-    // buffer while they land, then the staged registers go to the other LDS buffer (last read one barrier ago) and the
-    // last quarter of the MFMAs covers those writes.  One barrier per K step.
-    for (int t = 0; t < nT; ++t) {
-        const bool more = t + 1 < nT;
-        const int buf = t & 1;
-        if (more) load_tile();
+    int nSeq = 0;
+    for (int s = NI; s < g.nseg; ++s) nSeq += g.seg[s].kpad / BK;
+
+    // ---- interleaved group state (NI > 0): the NI segments are shifted views of ONE operand (same pointer and row
+    // stride, checked at launch), so a single descriptor based at the smallest shift serves all of them; per tile only a
+    // scalar byte delta and one validity bit per staged row change.
+    static_assert(NI <= 4, "NI");
+    const ASeg sg0 = g.seg[0];
+    const int sh0 = sg0.shift, sh1 = NI > 1 ? g.seg[NI > 1 ? 1 : 0].shift : sh0;
+    const int sh2 = NI > 2 ? g.seg[NI > 2 ? 2 : 0].shift : sh0, sh3 = NI > 3 ? g.seg[NI > 3 ? 3 : 0].shift : sh0;
+    auto shift_of = [&](int s) { return s == 0 ? sh0 : s == 1 ? sh1 : s == 2 ? sh2 : sh3; };
+    int min_shift = sh0;
+#pragma unroll
+    for (int s = 1; s < NI; ++s) min_shift = shift_of(s) < min_shift ? shift_of(s) : min_shift;
+    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(sg0.ptr + z * g.strideAz + ((long long)m0 + min_shift) * sg0.ld);
+    unsigned baseI[PA], vmaskI[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        baseI[p] = (unsigned)(((p * RPP + lrow) * (int)sg0.ld + c4) * 4);
+        unsigned vm = 0;
+#pragma unroll
+        for (int s = 0; s < NI; ++s) {
+            const int l2 = a_l[p] + shift_of(s);
+            vm |= (l2 >= 0 && l2 < g.L) ? (1u << s) : 0u;
+        }
+        vmaskI[p] = vm;
+    }
+    const int kI = sg0.k;
+    const int nI = NI > 0 ? NI * (sg0.kpad / BK) : 0;
+    const int ldb4 = (int)sg0.ld * 4;
+    int si = 0, kci = 0;                             // (segment, chunk) of the next interleaved tile to load
+    auto load_I = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {
+        const unsigned delta = (unsigned)((shift_of(si) - min_shift) * ldb4 + kci * BK * 4);
+        const bool kok = kci * BK + c4 < kI;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const bool ok = kok && ((vmaskI[p] >> si) & 1u);
+            ra[p] = buf_load4(rsI, ok ? baseI[p] + delta : OOB);
+        }
+        load_B(rb);
+        if (++si == NI) {
+            si = 0;
+            ++kci;
+        }
+    };
+    const int nAll = nI + nSeq;
+    int t_load = 0;                                  // index of the next tile to fetch
+    auto load_next = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {
+        if (t_load < nAll) {
+            if (NI > 0 && t_load < nI) load_I(ra, rb);
+            else load_seq(ra, rb);
+        }
+        ++t_load;
+    };
+    // One K step on LDS buffer `buf`: fetch tile t+2 into the free register stage, run all but the last quarter of the
+    // MFMAs of tile t, write tile t+1 (fetched one step ago) to the other LDS buffer, finish the MFMAs, barrier.
+    auto k_step = [&](int buf, bool has_next, f32x4 (&ra_ld)[PA], f32x4 (&rb_ld)[PB], const f32x4 (&ra_st)[PA],
+                      const f32x4 (&rb_st)[PB]) {
+        load_next(ra_ld, rb_ld);
 #pragma unroll
         for (int k8 = 0; k8 < BK / 8 - 1; ++k8) compute_chunk(buf, k8);
-        if (more) store_tile(buf ^ 1);
+        if (has_next) store_tile(buf ^ 1, ra_st, rb_st);
         compute_chunk(buf, BK / 8 - 1);
         __syncthreads();
+    };
+
+    if (nSeq > 0) enter_segment();
+    load_next(ra0, rb0);                             // tile 0
+    store_tile(0, ra0, rb0);
+    load_next(ra1, rb1);                             // tile 1 (kept in stage 1)
+    __syncthreads();
+    for (int t = 0; t < nAll; t += 2) {
+        k_step(0, t + 1 < nAll, ra0, rb0, ra1, rb1);                 // fetch t+2 -> stage 0, write t+1 from stage 1
+        if (t + 1 < nAll) k_step(1, t + 2 < nAll, ra1, rb1, ra0, rb0);   // fetch t+3 -> stage 1, write t+2 from stage 0
     }
 
     // ---------------- epilogue ----------------
@@ -300,7 +369,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
         }
 }
 
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG>
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
@@ -310,7 +379,14 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
     const int numMt8 = (numMt + 7) / 8 * 8;
     const size_t lds = (size_t)2 * (BM + BN) * LDSK * sizeof(float);
     if (g.split < g.N && g.split % BN != 0) return hipErrorInvalidValue;     // output side must be uniform per block
-    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG>;
+    if (NI > 0) {
+        if (g.nseg < NI) return hipErrorInvalidValue;
+        for (int i = 1; i < NI; ++i)
+            if (g.seg[i].k != g.seg[0].k || g.seg[i].kpad != g.seg[0].kpad || g.seg[i].ptr != g.seg[0].ptr ||
+                g.seg[i].ld != g.seg[0].ld)
+                return hipErrorInvalidValue;
+    }
+    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -328,9 +404,15 @@ enum { TAG_GENERIC = 0, TAG_WN_IN = 1, TAG_WN_RES_SKIP = 2 };
 #define TTS_WN_BK 16
 #define TTS_WN_OCC 2
 #endif
+#ifndef TTS_WN_RT
+#define TTS_WN_WR 4      // 4 x 1 waves, each RT x 4 tiles of 32x32: block tile (128 * RT) x 128
+#define TTS_WN_RT 2
+#endif
 inline hipError_t gemm_big(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<4, 1, 2, 4, 32, 1, TAG_GENERIC>(g, bz, s); }
-inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<4, 1, 2, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN>(g, 1, s); }
-inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<4, 1, 2, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_RES_SKIP>(g, 1, s); }
+// WN in-layer GEMM: the three conv taps are interleaved in K (weights packed to match, see pack_bt_kernel)
+constexpr int WN_TAPS = 3;
+inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS>(g, 1, s); }
+inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_RES_SKIP>(g, 1, s); }
 inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1, 32, 1, TAG_GENERIC>(g, bz, s); }
 
 }  // namespace ttsgemm

@@ -27,17 +27,24 @@ constexpr int UPK = 4 * 96;   // upsampling K: 4 taps x (80 padded to 96)
 
 // dst[n][koff + k] = src[k * src_ld + perm(n)]  for k < K   (Keras [K][N] kernel slice -> Bt rows)
 // perm: 0 identity; 1 WN gate interleave (per 128-row tile: 64 tanh channels then their 64 sigmoid partners)
+// taps > 1: src is [taps][K/taps][N] and the K axis of dst is tap-interleaved in chunks of `bk`:
+//   dst k = (c / bk) * taps * bk + tap * bk + c % bk     (matches gemm_f32_kernel's NI = taps tile order)
 __global__ void pack_bt_kernel(const float* __restrict__ src, int K, int src_ld, float* __restrict__ dst, int N,
-                               long long ldb, int koff, int perm) {
+                               long long ldb, int koff, int perm, int taps, int bk) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)N * K) return;
     const int n = (int)(idx / K), k = (int)(idx % K);
+    int kd = k;
+    if (taps > 1) {
+        const int cpt = K / taps, tap = k / cpt, c = k % cpt;
+        kd = (c / bk) * taps * bk + tap * bk + c % bk;
+    }
     int sn = n;
     if (perm == 1) {
         const int tile = n >> 7, q = n & 127;
         sn = q < 64 ? tile * 64 + q : C + tile * 64 + (q - 64);
     }
-    dst[(long long)n * ldb + koff + k] = src[(long long)k * src_ld + sn];
+    dst[(long long)n * ldb + koff + kd] = src[(long long)k * src_ld + sn];
 }
 
 __global__ void pack_bias_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst,
@@ -180,10 +187,10 @@ __global__ __launch_bounds__(256) void wn_end_kernel(const float* __restrict__ s
 }
 
 int pack_bt(tts_hip_engine* e, const float* d_src, int K, int src_ld, float* dst, int N, long long ldb, int koff,
-            int perm) {
+            int perm, int taps = 1, int bk = 0) {
     const long long total = (long long)N * K;
     hipLaunchKernelGGL(pack_bt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, d_src, K,
-                       src_ld, dst, N, ldb, koff, perm);
+                       src_ld, dst, N, ldb, koff, perm, taps, bk);
     HIPCHK(e, hipGetLastError());
     return TTS_HIP_OK;
 }
@@ -272,7 +279,7 @@ int waveglow_finalize(tts_hip_engine* e) {
             WGCHK(dev_alloc(e, (size_t)2 * C * KIN, &ly.in_Bt, wg.allocs, false));
             WGCHK(need(p + "/in_conv-" + si + "/kernel", {3, C, 2 * C}, &t));
             WGCHK(put(stage, t));
-            WGCHK(pack_bt(e, stage.f(), 3 * C, 2 * C, ly.in_Bt, 2 * C, KIN, 0, 1));
+            WGCHK(pack_bt(e, stage.f(), 3 * C, 2 * C, ly.in_Bt, 2 * C, KIN, 0, 1, WN_TAPS, TTS_WN_BK));
             HIPCHK(e, hipStreamSynchronize(e->stream));
             WGCHK(need(p + "/cond_layer-" + si + "/kernel", {1, NCOND, 2 * C}, &t));
             WGCHK(put(stage, t));
