@@ -50,6 +50,13 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get('TTS_HIP_LIBRARY') or LIB_PATH
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 and preloads it by path.  Two HIP runtimes in one process fight over
+    # the device ("No HIP GPUs are available" in whichever initialises second), so make sure torch's copy is the one
+    # already mapped when libtts_hip.so is opened: the dynamic linker then binds our DT_NEEDED soname to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise HipLibraryError(
             f'{p} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
