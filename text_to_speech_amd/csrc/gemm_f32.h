@@ -84,11 +84,19 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned by
 // BK = K extent of one LDS stage (16 or 32); OCC = blocks per CU the register/LDS budget is sized for.
 // NI > 0: the first NI segments (same k / kpad) are interleaved chunk-wise in K -- tile order (kc, s) -- so that the
 // shifted re-reads of one operand (the three conv taps of x) are one K step apart and hit L2 instead of HBM.
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0>
+// PIPE_REG: tiles are fetched into registers (two stages) and written to a padded, double-buffered LDS image.
+// PIPE_DMA: tiles are fetched straight into LDS (buffer_load ... lds, no VGPR round trip and no ds_write on the LDS
+//           pipe); the LDS image is unpadded 64-B rows, XOR-swizzled through the per-lane SOURCE address (a wave
+//           instruction writes 1 KiB linearly, cdna_hip_programming.md rule 21), triple buffered.
+enum { PIPE_REG = 0, PIPE_DMA = 1 };
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG>
 __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
-    constexpr int LDSK = BK + 4;            // padded LDS row (144 B / 80 B): conflict-free ds_read_b128
+    constexpr bool DMA = PIPE == PIPE_DMA;
+    static_assert(!DMA || BK == 16, "the LDS-DMA image is laid out for 64-byte rows");
+    constexpr int LDSK = DMA ? BK : BK + 4; // LDS row in floats: padded (144 B / 80 B) or swizzled 64 B
+    constexpr int NBUF = DMA ? 3 : 2;
     constexpr int TPR = BK / 4;             // threads (float4) per tile row
     constexpr int RPP = 256 / TPR;          // rows staged per pass of the 256 threads
     constexpr int PA = BM / RPP;            // float4 loads per thread for the A tile
@@ -97,8 +105,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     static_assert(BK == 16 || BK == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                          // [2][BM][LDSK]
-    float* Bs = smem + 2 * BM * LDSK;          // [2][BN][LDSK]
+    float* As = smem;                          // [NBUF][BM][LDSK]
+    float* Bs = smem + NBUF * BM * LDSK;       // [NBUF][BN][LDSK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -119,7 +127,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     const long long z = blockIdx.z;
 
     const int lrow = tid / TPR;         // row inside a staging pass
-    const int c4 = (tid % TPR) * 4;     // k offset of this thread's float4
+    // k offset of this thread's float4.  DMA: LDS slot (row, c') receives global chunk c' ^ ((row >> 2) & 3)
+    const int c4 = DMA ? (((tid & 3) ^ ((tid >> 4) & 3)) * 4) : (tid % TPR) * 4;
     const int li = lane & 31, lh = lane >> 5;
 
     // ---- accumulators start from bias (+ the previous output value for read-modify-write epilogues), so the
@@ -199,57 +208,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
         seg_offsets(sg, a_off);
     };
 
-    // two register stages: tile t+1 waits in one while tile t+2 is being fetched into the other (prefetch distance of
-    // two K steps: an HBM / Infinity-Cache miss has ~2 K steps to land before its ds_write needs it)
-    f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
-    auto load_B = [&](f32x4 (&rb)[PB]) {
-        const unsigned kg = (unsigned)(kglob * 4);
-#pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = buf_load4(rsB, b_off[p] + kg);
-        kglob += BK;
-    };
-    auto load_seq = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {       // next tile of the sequential segments
-        const unsigned kb = (unsigned)(kc_cur * BK * 4);
-        const bool kok = kc_cur * BK + c4 < seg_k;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) ra[p] = buf_load4(rsA, kok ? a_off[p] + kb : OOB);
-        load_B(rb);
-        if (++kc_cur * BK >= seg_kpad) {
-            kc_cur = 0;
-            if (++s_cur < g.nseg) enter_segment();
-        }
-    };
-    auto store_tile = [&](int buf, const f32x4 (&ra)[PA], const f32x4 (&rb)[PB]) {
-        float* a = As + buf * BM * LDSK;
-        float* b = Bs + buf * BN * LDSK;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(a + (p * RPP + lrow) * LDSK + c4) = ra[p];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(b + (p * RPP + lrow) * LDSK + c4) = rb[p];
-    };
-    auto compute_chunk = [&](int buf, int k8) {
-        const float* a = As + buf * BM * LDSK + (wr * RT * 32 + li) * LDSK + lh * 4 + k8 * 8;
-        const float* b = Bs + buf * BN * LDSK + (wc * CT * 32 + li) * LDSK + lh * 4 + k8 * 8;
-        f32x4 fa[RT], fb[CT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
-#pragma unroll
-        for (int j = 0; j < CT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
-    };
-
+    // ---- tile fetch: the same address generation feeds either register stages (PIPE_REG) or LDS-DMA (PIPE_DMA);
+    // `emit(isA, p, rsrc, voffset)` is the sink.
     int nSeq = 0;
     for (int s = NI; s < g.nseg; ++s) nSeq += g.seg[s].kpad / BK;
 
-    // ---- interleaved group state (NI > 0): the NI segments are shifted views of ONE operand (same pointer and row
-    // stride, checked at launch), so a single descriptor based at the smallest shift serves all of them; per tile only a
-    // scalar byte delta and one validity bit per staged row change.
+    // interleaved group state (NI > 0): the NI segments are shifted views of ONE operand (same pointer and row stride,
+    // checked at launch), so a single descriptor based at the smallest shift serves all of them; per tile only a scalar
+    // byte delta and one validity bit per staged row change.
     static_assert(NI <= 4, "NI");
     const ASeg sg0 = g.seg[0];
     const int sh0 = sg0.shift, sh1 = NI > 1 ? g.seg[NI > 1 ? 1 : 0].shift : sh0;
@@ -275,49 +241,127 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     const int nI = NI > 0 ? NI * (sg0.kpad / BK) : 0;
     const int ldb4 = (int)sg0.ld * 4;
     int si = 0, kci = 0;                             // (segment, chunk) of the next interleaved tile to load
-    auto load_I = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {
-        const unsigned delta = (unsigned)((shift_of(si) - min_shift) * ldb4 + kci * BK * 4);
-        const bool kok = kci * BK + c4 < kI;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const bool ok = kok && ((vmaskI[p] >> si) & 1u);
-            ra[p] = buf_load4(rsI, ok ? baseI[p] + delta : OOB);
-        }
-        load_B(rb);
-        if (++si == NI) {
-            si = 0;
-            ++kci;
-        }
-    };
     const int nAll = nI + nSeq;
     int t_load = 0;                                  // index of the next tile to fetch
-    auto load_next = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {
+
+    auto fetch_next = [&](auto&& emit) {             // issues the loads of tile `t_load` (if any) and advances
         if (t_load < nAll) {
-            if (NI > 0 && t_load < nI) load_I(ra, rb);
-            else load_seq(ra, rb);
+            if (NI > 0 && t_load < nI) {
+                const unsigned delta = (unsigned)((shift_of(si) - min_shift) * ldb4 + kci * BK * 4);
+                const bool kok = kci * BK + c4 < kI;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const bool ok = kok && ((vmaskI[p] >> si) & 1u);
+                    emit(true, p, rsI, ok ? baseI[p] + delta : OOB);
+                }
+                if (++si == NI) {
+                    si = 0;
+                    ++kci;
+                }
+            } else {
+                const unsigned kb = (unsigned)(kc_cur * BK * 4);
+                const bool kok = kc_cur * BK + c4 < seg_k;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) emit(true, p, rsA, kok ? a_off[p] + kb : OOB);
+                if (++kc_cur * BK >= seg_kpad) {
+                    kc_cur = 0;
+                    if (++s_cur < g.nseg) enter_segment();
+                }
+            }
+            const unsigned kg = (unsigned)(kglob * 4);
+#pragma unroll
+            for (int p = 0; p < PB; ++p) emit(false, p, rsB, b_off[p] + kg);
+            kglob += BK;
         }
         ++t_load;
     };
-    // One K step on LDS buffer `buf`: fetch tile t+2 into the free register stage, run all but the last quarter of the
-    // MFMAs of tile t, write tile t+1 (fetched one step ago) to the other LDS buffer, finish the MFMAs, barrier.
-    auto k_step = [&](int buf, bool has_next, f32x4 (&ra_ld)[PA], f32x4 (&rb_ld)[PB], const f32x4 (&ra_st)[PA],
-                      const f32x4 (&rb_st)[PB]) {
-        load_next(ra_ld, rb_ld);
+
+    // ---- MFMA on one LDS buffer
+    const int xr = (li >> 2) & 3;                    // DMA image: chunk XOR of this lane's operand rows
+    auto compute_chunk = [&](int buf, int k8) {
+        const int koff = DMA ? (((2 * k8 + lh) ^ xr) * 4) : (lh * 4 + k8 * 8);
+        const float* a = As + buf * BM * LDSK + (wr * RT * 32 + li) * LDSK + koff;
+        const float* b = Bs + buf * BN * LDSK + (wc * CT * 32 + li) * LDSK + koff;
+        f32x4 fa[RT], fb[CT];
 #pragma unroll
-        for (int k8 = 0; k8 < BK / 8 - 1; ++k8) compute_chunk(buf, k8);
-        if (has_next) store_tile(buf ^ 1, ra_st, rb_st);
-        compute_chunk(buf, BK / 8 - 1);
-        __syncthreads();
+        for (int i = 0; i < RT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
     };
 
     if (nSeq > 0) enter_segment();
-    load_next(ra0, rb0);                             // tile 0
-    store_tile(0, ra0, rb0);
-    load_next(ra1, rb1);                             // tile 1 (kept in stage 1)
-    __syncthreads();
-    for (int t = 0; t < nAll; t += 2) {
-        k_step(0, t + 1 < nAll, ra0, rb0, ra1, rb1);                 // fetch t+2 -> stage 0, write t+1 from stage 1
-        if (t + 1 < nAll) k_step(1, t + 2 < nAll, ra1, rb1, ra0, rb0);   // fetch t+3 -> stage 1, write t+2 from stage 0
+    if constexpr (DMA) {
+        // Three LDS buffers.  Step t: issue tile t+2's DMA into the buffer read at step t-1 (every wave has passed the
+        // barrier that ended that step), run tile t's MFMAs, then wait until all but the newest tile's DMA have landed
+        // (counted vmcnt: tile t+1 is in LDS) and barrier.  No VGPR staging, no ds_write.
+        constexpr int LT = PA + PB;                  // DMA instructions per tile per wave
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        auto dma_tile = [&](int buf) {
+            fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff) {
+                // wave-uniform LDS base of this instruction's 16 rows; lane l lands at base + 16 * l
+                float* dst = (isA ? As + buf * BM * LDSK : Bs + buf * BN * LDSK) + (p * RPP + wave * 16) * LDSK;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+            });
+        };
+        dma_tile(0);
+        dma_tile(1);                                 // (no-op when there is a single tile)
+        if (nAll > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int buf = 0, bufn = 2;                       // buffer of tile t, buffer for tile t+2
+        for (int t = 0; t < nAll; ++t) {
+            dma_tile(bufn);
+#pragma unroll
+            for (int k8 = 0; k8 < BK / 8; ++k8) compute_chunk(buf, k8);
+            if (t + 2 < nAll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf = buf == 2 ? 0 : buf + 1;
+            bufn = bufn == 2 ? 0 : bufn + 1;
+        }
+    } else {
+        // Two register stages: tile t+1 waits in one while tile t+2 is being fetched into the other (prefetch distance
+        // of two K steps).  Step t on LDS buffer `buf`: fetch tile t+2 into the free stage, run all but the last
+        // quarter of the MFMAs of tile t, write tile t+1 to the other LDS buffer, finish the MFMAs, barrier.
+        f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+        auto load_next = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {
+            fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff) {
+                if (isA) ra[p] = buf_load4(rs, voff);
+                else rb[p] = buf_load4(rs, voff);
+            });
+        };
+        auto store_tile = [&](int buf, const f32x4 (&ra)[PA], const f32x4 (&rb)[PB]) {
+            float* a = As + buf * BM * LDSK;
+            float* b = Bs + buf * BN * LDSK;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(a + (p * RPP + lrow) * LDSK + c4) = ra[p];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(b + (p * RPP + lrow) * LDSK + c4) = rb[p];
+        };
+        auto k_step = [&](int buf, bool has_next, f32x4 (&ra_ld)[PA], f32x4 (&rb_ld)[PB], const f32x4 (&ra_st)[PA],
+                          const f32x4 (&rb_st)[PB]) {
+            load_next(ra_ld, rb_ld);
+#pragma unroll
+            for (int k8 = 0; k8 < BK / 8 - 1; ++k8) compute_chunk(buf, k8);
+            if (has_next) store_tile(buf ^ 1, ra_st, rb_st);
+            compute_chunk(buf, BK / 8 - 1);
+            __syncthreads();
+        };
+        load_next(ra0, rb0);                             // tile 0
+        store_tile(0, ra0, rb0);
+        load_next(ra1, rb1);                             // tile 1 (kept in stage 1)
+        __syncthreads();
+        for (int t = 0; t < nAll; t += 2) {
+            k_step(0, t + 1 < nAll, ra0, rb0, ra1, rb1);                 // fetch t+2 -> stage 0, write t+1 from stage 1
+            if (t + 1 < nAll) k_step(1, t + 2 < nAll, ra1, rb1, ra0, rb0);   // fetch t+3 -> stage 1, write t+2 from stage 0
+        }
     }
 
     // ---------------- epilogue ----------------
@@ -369,15 +413,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
         }
 }
 
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0>
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
-    constexpr int LDSK = BK + 4;
+    constexpr int LDSK = PIPE == PIPE_DMA ? BK : BK + 4;
+    constexpr int NBUF = PIPE == PIPE_DMA ? 3 : 2;
     const int numNt = (g.N + BN - 1) / BN;
     const int numMt = (g.M + BM - 1) / BM;
     const int numMt8 = (numMt + 7) / 8 * 8;
-    const size_t lds = (size_t)2 * (BM + BN) * LDSK * sizeof(float);
+    const size_t lds = (size_t)NBUF * (BM + BN) * LDSK * sizeof(float);
     if (g.split < g.N && g.split % BN != 0) return hipErrorInvalidValue;     // output side must be uniform per block
     if (NI > 0) {
         if (g.nseg < NI) return hipErrorInvalidValue;
@@ -386,7 +431,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
                 g.seg[i].ld != g.seg[0].ld)
                 return hipErrorInvalidValue;
     }
-    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI>;
+    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -408,11 +453,14 @@ enum { TAG_GENERIC = 0, TAG_WN_IN = 1, TAG_WN_RES_SKIP = 2 };
 #define TTS_WN_WR 4      // 4 x 1 waves, each RT x 4 tiles of 32x32: block tile (128 * RT) x 128
 #define TTS_WN_RT 2
 #endif
+#ifndef TTS_WN_PIPE
+#define TTS_WN_PIPE PIPE_DMA
+#endif
 inline hipError_t gemm_big(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<4, 1, 2, 4, 32, 1, TAG_GENERIC>(g, bz, s); }
 // WN in-layer GEMM: the three conv taps are interleaved in K (weights packed to match, see pack_bt_kernel)
 constexpr int WN_TAPS = 3;
-inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS>(g, 1, s); }
-inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_RES_SKIP>(g, 1, s); }
+inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
 inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1, 32, 1, TAG_GENERIC>(g, bz, s); }
 
 }  // namespace ttsgemm
