@@ -45,16 +45,16 @@ struct DevBuf {
 struct WgLayerDev {
     float* in_Bt = nullptr;     // [1024 (tanh/sigmoid interleaved per 128-tile)][2176 = 3*512 taps + 640 cond]
     float* in_bias = nullptr;   // [1024] in_conv bias + cond bias, same row order
-    float* rs_Bt = nullptr;     // [rs_n][512]
-    float* rs_bias = nullptr;   // [rs_n]
+    float* rs_Bt = nullptr;     // [512][512] residual half of res_skip (layers 0..6)
+    float* rs_bias = nullptr;   // [512]
     int rs_n = 0;
 };
 struct WgFlowDev {
     int n_rem = 0, n_half = 0;
     float* start_w = nullptr;   // [n_half][512]
     float* start_b = nullptr;   // [512]
-    float* end_w = nullptr;     // [2*n_half][512]
-    float* end_b = nullptr;     // [2*n_half]
+    float* end_w = nullptr;     // [8 layers][8][512] skip halves folded into the end conv (rows >= 2*n_half are zero)
+    float* end_b = nullptr;     // [8]
     float* inv = nullptr;       // [n_rem][n_rem]  out = audio @ inv
     WgLayerDev layer[8];
 };

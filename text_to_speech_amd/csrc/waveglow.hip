@@ -5,12 +5,18 @@
 //
 // HBM layout (all float32, channels-last, M = B * L positions, L = T * 32 groups of 8 samples):
 //   spect [M][640]   upsampled + regrouped conditioning (channel = mel * 8 + g), written once per call
-//   x     [M][512]   WN residual stream, updated in place by the res/skip GEMM epilogue
-//   acts  [M][512]   gated activations tanh * sigmoid, produced by the in-layer GEMM epilogue
-//   skip  [M][512]   running sum of skip outputs
+//   x     [M][512]   WN residual stream, updated in place by the residual GEMM epilogue
+//   acts  [8][M][512] gated activations tanh * sigmoid of the 8 layers of the current flow (in-layer GEMM epilogue)
 //   audio [M][8]     current flow state in the first n_rem columns; after the last flow it IS the output [B][L*8]
 // Per flow: start (VALU) -> 8 x { in-layer implicit GEMM (K = 3 taps * 512 + 640 cond, N = 1024, gate epilogue),
-// res/skip GEMM (K = 512, N = 1024) } -> end 1x1 + affine inverse + inverse 1x1 conv (one wave per position).
+// residual GEMM (K = 512, N = 512; not for the last layer) } -> folded skip/end + affine inverse + inverse 1x1 conv.
+//
+// Skip path folding (exact algebra, done once at load time): the reference sums the skip halves of the 8 res_skip convs
+// and feeds the sum to the `end` 1x1 conv (waveglow_arch.py:129-141).  Both are linear, so
+//     end(sum_i skip_i) = sum_i acts_i @ (W_skip_i @ W_end) + (sum_i b_skip_i) @ W_end + b_end .
+// The 512 -> 512 skip GEMMs (and the whole res_skip conv of the last layer) disappear -- 9.6 % of the WN FLOPs and the
+// read-modify-write of a [M][512] skip buffer per layer -- and are replaced by one [M, 8*512] x [8*512, 2h] product per
+// flow (h <= 4), computed by the HBM-bound wn_end_fold_kernel straight from the stored activations.
 #include "engine.h"
 #include "gemm_f32.h"
 
@@ -112,77 +118,92 @@ __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __
     *reinterpret_cast<f32x4*>(x + m * C + c) = acc;
 }
 
-// One wave per position: end 1x1 (512 -> 2h), affine inverse, inverse 1x1 conv, optional early-z prepend.
-//   waveglow_arch.py:141 (end), :284-290, :292-304
-__global__ __launch_bounds__(256) void wn_end_kernel(const float* __restrict__ skip, const float* __restrict__ end_w,
-                                                     const float* __restrict__ end_b, const float* __restrict__ inv,
-                                                     float* __restrict__ audio_io, float* __restrict__ audio_out,
-                                                     const float* __restrict__ z, int zoff, int n_early, float sigma,
-                                                     long long M, int h, int rows_per_wave) {
+// Folded skip/end conv + affine inverse + inverse 1x1 conv (+ early-z prepend), RPW positions per wave.
+//   out[m][o] = sum_layer sum_c acts[layer][m][c] * wfold[layer][o][c] + bfold[o]          (waveglow_arch.py:129-141)
+//   audio_1 = (audio_1 - b) / exp(s); audio = [audio_0, audio_1] @ inv; prepend sigma * z_early   (:284-304)
+// Lane l owns channels 8l..8l+7; per layer the lane's 8x8 slice of wfold sits in registers and is reused for the RPW
+// rows; the RPW*8 partial sums are reduced with the lane-halving exchange (63 shuffles for 64 values).
+constexpr int RPW = 8;
+__global__ __launch_bounds__(256) void wn_end_fold_kernel(const float* __restrict__ acts, long long layer_stride,
+                                                          const float* __restrict__ wfold,
+                                                          const float* __restrict__ bfold,
+                                                          const float* __restrict__ inv, float* __restrict__ audio_io,
+                                                          float* __restrict__ audio_out, const float* __restrict__ z,
+                                                          int zoff, int n_early, float sigma, long long M, int h) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n2 = 2 * h, cch = 2 * h;       // end-conv outputs; flow channels
-    // this lane's slice of the end kernel: channels lane*8 .. lane*8+7 of every output row
-    float we[8][8];
+    const long long m0 = wave * RPW;
+    if (m0 >= M) return;
+    const int cch = 2 * h;
+    float acc[RPW * 8];                                   // index r * 8 + o
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        if (o < n2) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(end_w + o * C + lane * 8);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(end_w + o * C + lane * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                we[o][j] = w0[j];
-                we[o][4 + j] = w1[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) we[o][j] = 0.f;
-        }
-    }
-    for (int r = 0; r < rows_per_wave; ++r) {
-        const long long m = wave * rows_per_wave + r;
-        if (m >= M) return;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(skip + m * C + lane * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(skip + m * C + lane * 8 + 4);
-        float out[8];
+    for (int i = 0; i < RPW * 8; ++i) acc[i] = 0.f;
+    for (int layer = 0; layer < 8; ++layer) {
+        f32x4 w0[8], w1[8], a0[RPW], a1[RPW];
+        const float* wl = wfold + ((long long)layer * 8) * C + lane * 8;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            float p = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p = fmaf(v0[j], we[o][j], p);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p = fmaf(v1[j], we[o][4 + j], p);
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) p += __shfl_xor(p, s, 64);
-            out[o] = p;
+            w0[o] = *reinterpret_cast<const f32x4*>(wl + o * C);
+            w1[o] = *reinterpret_cast<const f32x4*>(wl + o * C + 4);
         }
-        // every lane now holds the 2h end-conv outputs; lane 0 finishes the (tiny) affine + 1x1 step
-        if (lane == 0) {
-            float a[8], y[8];
+        const float* al = acts + layer * layer_stride + lane * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = j < cch ? audio_io[m * 8 + j] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < h) y[j] = a[j];
-                else if (j < cch) {
-                    const float bb = out[j - h] + end_b[j - h];
-                    const float ss = out[j] + end_b[j];
-                    y[j] = (a[j] - bb) / expf(ss);
-                } else y[j] = 0.f;
-            }
-            float res[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float t = 0.f;
-                if (c < cch) {
-                    for (int j = 0; j < cch; ++j) t = fmaf(y[j], inv[j * cch + c], t);
-                }
-                res[c] = t;
-            }
-            float* dst = audio_out + m * 8;
-            for (int j = 0; j < n_early; ++j) dst[j] = z ? sigma * z[m * 8 + zoff + j] : 0.f;
-            for (int c = 0; c < cch; ++c) dst[n_early + c] = res[c];
+        for (int r = 0; r < RPW; ++r) {
+            const long long m = m0 + r < M ? m0 + r : M - 1;       // clamp: tail rows are computed but never stored
+            a0[r] = *reinterpret_cast<const f32x4*>(al + m * C);
+            a1[r] = *reinterpret_cast<const f32x4*>(al + m * C + 4);
         }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float p = acc[r * 8 + o];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p = fmaf(a0[r][j], w0[o][j], p);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p = fmaf(a1[r][j], w1[o][j], p);
+                acc[r * 8 + o] = p;
+            }
+    }
+    // 64 values over 64 lanes: after masks 32..1 lane l holds the full sum of index l = r * 8 + o
+#pragma unroll
+    for (int half = RPW * 4, msk = 32; half >= 1; half >>= 1, msk >>= 1) {
+        const bool hi = (lane & msk) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float send = hi ? acc[i] : acc[i + half];
+            const float keep = hi ? acc[i + half] : acc[i];
+            acc[i] = keep + __shfl_xor(send, msk, 64);
+        }
+    }
+    const float mine = acc[0] + bfold[lane & 7];
+    // lanes 8r .. 8r+7 hold out[r][0..7]; lane 8r finishes position m0 + r
+    float out[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) out[o] = __shfl(mine, (lane & ~7) + o, 64);
+    const long long m = m0 + (lane >> 3);
+    if ((lane & 7) == 0 && m < M) {
+        float a[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = j < cch ? audio_io[m * 8 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < h) y[j] = a[j];
+            else if (j < cch) y[j] = (a[j] - out[j - h]) / expf(out[j]);
+            else y[j] = 0.f;
+        }
+        float res[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float t = 0.f;
+            if (c < cch) {
+                for (int j = 0; j < cch; ++j) t = fmaf(y[j], inv[j * cch + c], t);
+            }
+            res[c] = t;
+        }
+        float* dst = audio_out + m * 8;
+        for (int j = 0; j < n_early; ++j) dst[j] = z ? sigma * z[m * 8 + zoff + j] : 0.f;
+        for (int c = 0; c < cch; ++c) dst[n_early + c] = res[c];
     }
 }
 
@@ -293,24 +314,51 @@ int waveglow_finalize(tts_hip_engine* e) {
             hipLaunchKernelGGL(pack_bias_kernel, dim3(4), dim3(256), 0, e->stream, stage2.f(), stage2.f() + 2 * C,
                                ly.in_bias, 2 * C, 1);
             HIPCHK(e, hipStreamSynchronize(e->stream));
-            ly.rs_n = i < 7 ? 2 * C : C;
-            WGCHK(need(p + "/res_skip_conv-" + si + "/kernel", {1, C, ly.rs_n}, &t));
-            WGCHK(dev_alloc(e, (size_t)ly.rs_n * C, &ly.rs_Bt, wg.allocs, false));
-            WGCHK(put(stage, t));
-            WGCHK(pack_bt(e, stage.f(), C, ly.rs_n, ly.rs_Bt, ly.rs_n, C, 0, 0));
-            HIPCHK(e, hipStreamSynchronize(e->stream));
-            WGCHK(need(p + "/res_skip_conv-" + si + "/bias", {ly.rs_n}, &t));
-            WGCHK(upload(e, t->data.data(), t->numel(), &ly.rs_bias, wg.allocs));
+            // res_skip conv: keep only the residual half as a GEMM operand (layers 0..6); the skip half is folded below
+            const int rs_full = i < 7 ? 2 * C : C;
+            WGCHK(need(p + "/res_skip_conv-" + si + "/kernel", {1, C, rs_full}, &t));
+            WGCHK(need(p + "/res_skip_conv-" + si + "/bias", {rs_full}, &t2));
+            ly.rs_n = i < 7 ? C : 0;
+            if (i < 7) {
+                WGCHK(dev_alloc(e, (size_t)C * C, &ly.rs_Bt, wg.allocs, false));
+                WGCHK(put(stage, t));
+                WGCHK(pack_bt(e, stage.f(), C, rs_full, ly.rs_Bt, C, C, 0, 0));      // rows n < 512 = residual outputs
+                HIPCHK(e, hipStreamSynchronize(e->stream));
+                WGCHK(upload(e, t2->data.data(), C, &ly.rs_bias, wg.allocs));
+            }
         }
-        WGCHK(need(p + "/end_conv/kernel", {1, C, 2 * n_half}, &t));
         {
-            std::vector<float> tr((size_t)2 * n_half * C);
-            for (int c = 0; c < C; ++c)
-                for (int o = 0; o < 2 * n_half; ++o) tr[(size_t)o * C + c] = t->data[(size_t)c * 2 * n_half + o];
-            WGCHK(upload(e, tr.data(), tr.size(), &fl.end_w, wg.allocs));
+            // fold: wfold[i][o][c] = sum_s W_skip_i[c][s] * W_end[s][o];  bfold[o] = sum_i b_skip_i @ W_end + b_end
+            const HostTensor *we, *be;
+            WGCHK(need(p + "/end_conv/kernel", {1, C, 2 * n_half}, &we));
+            WGCHK(need(p + "/end_conv/bias", {2 * n_half}, &be));
+            const int no = 2 * n_half;
+            std::vector<float> wf((size_t)8 * 8 * C, 0.f), bf(8, 0.f);
+            std::vector<double> bsum(no, 0.0);
+            for (int o = 0; o < no; ++o) bsum[o] = be->data[o];
+            for (int i = 0; i < 8; ++i) {
+                const HostTensor* wk = find_tensor(e, p + "/res_skip_conv-" + std::to_string(i) + "/kernel");
+                const HostTensor* bk = find_tensor(e, p + "/res_skip_conv-" + std::to_string(i) + "/bias");
+                const int rs_full = i < 7 ? 2 * C : C, soff = i < 7 ? C : 0;
+                std::vector<double> row(no);
+                for (int c = 0; c < C; ++c) {
+                    for (int o = 0; o < no; ++o) row[o] = 0.0;
+                    const float* ws = wk->data.data() + (size_t)c * rs_full + soff;
+                    for (int sidx = 0; sidx < C; ++sidx) {
+                        const double wv = ws[sidx];
+                        const float* wend = we->data.data() + (size_t)sidx * no;
+                        for (int o = 0; o < no; ++o) row[o] += wv * (double)wend[o];
+                    }
+                    for (int o = 0; o < no; ++o) wf[((size_t)i * 8 + o) * C + c] = (float)row[o];
+                }
+                for (int sidx = 0; sidx < C; ++sidx)
+                    for (int o = 0; o < no; ++o)
+                        bsum[o] += (double)bk->data[soff + sidx] * (double)we->data[(size_t)sidx * no + o];
+            }
+            for (int o = 0; o < no; ++o) bf[o] = (float)bsum[o];
+            WGCHK(upload(e, wf.data(), wf.size(), &fl.end_w, wg.allocs));
+            WGCHK(upload(e, bf.data(), bf.size(), &fl.end_b, wg.allocs));
         }
-        WGCHK(need(p + "/end_conv/bias", {2 * n_half}, &t));
-        WGCHK(upload(e, t->data.data(), t->numel(), &fl.end_b, wg.allocs));
         // Invertible1x1Conv.build_inverse (invertible_conv.py:41-47): W = kernel[0]^T, W_inverse = inv(W)^T, and the
         // reverse conv (kernel layout [1][in][out]) computes out = audio @ W_inverse = audio @ inv(kernel[0]^T)^T.
         WGCHK(need("waveglow/invertible_conv-" + std::to_string(k) + "/conv/kernel", {1, n_rem, n_rem}, &t));
@@ -360,8 +408,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     const long long M = (long long)B * L;
     HIPCHK(e, wg.spect.ensure((size_t)M * NCOND * 4));
     HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
-    HIPCHK(e, wg.acts.ensure((size_t)M * C * 4));
-    HIPCHK(e, wg.skip.ensure((size_t)M * C * 4));
+    HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));      // activations of the 8 layers of one flow
     HIPCHK(e, wg.audio.ensure((size_t)M * 8 * 4));
     hipStream_t st = e->stream;
 
@@ -419,49 +466,41 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.ldb = KIN;
             g.bias = ly.in_bias;
             g.mode = EPI_GATE;
-            g.out0 = wg.acts.f();
+            float* acts_i = wg.acts.f() + (size_t)i * M * C;
+            g.out0 = acts_i;
             g.ld0 = C;
             g.split = 2 * C;
             timing_begin(e, 0);
             HIPCHK(e, gemm_wn_in(g, st));
             timing_end(e);
 
-            GemmArgs r{};
-            r.M = (int)M;
-            r.N = ly.rs_n;
-            r.L = (int)M;
-            r.nseg = 1;
-            r.seg[0] = ASeg{wg.acts.f(), C, 0, C, C};
-            r.Bt = ly.rs_Bt;
-            r.ldb = C;
-            r.bias = ly.rs_bias;
-            r.mode = EPI_LINEAR;
-            r.act = ACT_NONE;
-            if (i < 7) {                 // res -> x (+=), skip -> skip (= for the first layer, += after)
+            if (i < 7) {                 // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
+                GemmArgs r{};
+                r.M = (int)M;
+                r.N = C;
+                r.L = (int)M;
+                r.nseg = 1;
+                r.seg[0] = ASeg{acts_i, C, 0, C, C};
+                r.Bt = ly.rs_Bt;
+                r.ldb = C;
+                r.bias = ly.rs_bias;
+                r.mode = EPI_LINEAR;
+                r.act = ACT_NONE;
                 r.split = C;
                 r.out0 = wg.x.f();
                 r.ld0 = C;
                 r.acc0 = 1;
-                r.out1 = wg.skip.f();
-                r.ld1 = C;
-                r.acc1 = i > 0;
-            } else {                     // last layer: 512 outputs, all skip
-                r.split = C;
-                r.out0 = wg.skip.f();
-                r.ld0 = C;
-                r.acc0 = 1;
-                r.out1 = nullptr;
+                timing_begin(e, 1);
+                HIPCHK(e, gemm_wn_res_skip(r, st));
+                timing_end(e);
             }
-            timing_begin(e, 1);
-            HIPCHK(e, gemm_wn_res_skip(r, st));
-            timing_end(e);
         }
         const bool early = (k % 4 == 0) && k > 0;
         float* dst = (k == 0) ? d_audio : wg.audio.f();
-        const int rows_per_wave = 8;
-        const long long waves = (M + rows_per_wave - 1) / rows_per_wave;
-        hipLaunchKernelGGL(wn_end_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, wg.skip.f(), fl.end_w,
-                           fl.end_b, fl.inv, wg.audio.f(), dst, d_z, zoff, early ? 2 : 0, sigma, M, h, rows_per_wave);
+        const long long waves = (M + RPW - 1) / RPW;
+        hipLaunchKernelGGL(wn_end_fold_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, wg.acts.f(),
+                           (long long)M * C, fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, d_z, zoff, early ? 2 : 0,
+                           sigma, M, h);
         HIPCHK(e, hipGetLastError());
         if (early) zoff += 2;
     }
