@@ -193,7 +193,7 @@ def main():
                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic_bytes(B, T),
                         'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
                         'algorithmic_bytes': (M * (512 + 640 + 512) + 1024 * 2176) * 4.0,
-                        'kernel': 'gemm_f32_kernel<4,1,2,4> (WN in-layer implicit GEMM)', 'launches_timed': launches,
+                        'kernel': 'gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow)', 'launches_timed': launches,
                         'avg_launch_us': avg_us}
         cpu = None
         if args.cpu_frames > 0:

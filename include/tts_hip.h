@@ -87,8 +87,8 @@ int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float*
 
 /* ---- measurement hooks (used by bench.py; no effect on results) -------------------------------------------------
  * Average duration in microseconds of the dominant kernel's launches (HIP events on the engine's stream) since the
- * last reset, and how many launches were timed.  kind: 0 = WaveGlow WN in-layer GEMM, 1 = WN res/skip GEMM,
- * 2 = Tacotron2 decoder step.  Timing is off unless enabled (events perturb nothing but cost a few us each).        */
+ * last reset, and how many launches were timed.  kind: 0 = WaveGlow WN in-layer GEMM (layers 1..7 of a flow: K = 2176),
+ * 1 = WN residual GEMM, 2 = Tacotron2 decoder step, 3 = first WN layer of a flow (start conv composed: K = 688).  Timing is off unless enabled (events perturb nothing but cost a few us each).        */
 int tts_hip_kernel_timing(tts_hip_engine* e, int enable);
 int tts_hip_kernel_time_us(tts_hip_engine* e, int kind, double* avg_us, int64_t* launches);
 int tts_hip_synchronize(tts_hip_engine* e);

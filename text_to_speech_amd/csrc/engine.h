@@ -64,7 +64,7 @@ struct WaveGlowDev {
     float* up_bias = nullptr;   // [640]
     WgFlowDev flow[12];
     std::vector<void*> allocs;
-    DevBuf spect, x, acts, skip, audio, io_mel, io_z, io_out;
+    DevBuf spect, x, acts, audio, a0p, io_mel, io_z, io_out;
 };
 
 // ---------------------------------------------------------------- Tacotron2

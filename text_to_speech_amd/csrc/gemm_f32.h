@@ -444,7 +444,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
 }
 
 // Tile configurations: BIG = 256x128 (WN layers, upsampling); SMALL = 64x64 (Tacotron2-sized problems).
-enum { TAG_GENERIC = 0, TAG_WN_IN = 1, TAG_WN_RES_SKIP = 2 };
+enum { TAG_GENERIC = 0, TAG_WN_IN = 1, TAG_WN_RES_SKIP = 2, TAG_WN_IN0 = 3 };
 #ifndef TTS_WN_BK
 #define TTS_WN_BK 16
 #define TTS_WN_OCC 2
@@ -460,6 +460,8 @@ inline hipError_t gemm_big(const GemmArgs& g, int bz, hipStream_t s) { return la
 // WN in-layer GEMM: the three conv taps are interleaved in K (weights packed to match, see pack_bt_kernel)
 constexpr int WN_TAPS = 3;
 inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+// first layer of a flow (start conv composed into the taps: K = 48 + 640); own TAG so profiles list it separately
+inline hipError_t gemm_wn_in0(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
 inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1, 32, 1, TAG_GENERIC>(g, bz, s); }
 

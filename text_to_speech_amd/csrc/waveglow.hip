@@ -29,6 +29,7 @@ namespace {
 constexpr int C = 512;        // n_channels
 constexpr int NCOND = 640;    // n_mel * n_group
 constexpr int KIN = 3 * C + NCOND;
+constexpr int KIN0 = 3 * 16 + NCOND;    // first layer of a flow: taps act on [audio_0 | 1] (16-float rows)
 constexpr int UPK = 4 * 96;   // upsampling K: 4 taps x (80 padded to 96)
 
 // dst[n][koff + k] = src[k * src_ld + perm(n)]  for k < K   (Keras [K][N] kernel slice -> Bt rows)
@@ -100,12 +101,24 @@ __global__ void init_audio_kernel(const float* __restrict__ z, float sigma, floa
 }
 
 // x[m][c] = sum_{j < h} audio[m][j] * w[j][c] + b[c]      (start 1x1 conv, waveglow_arch.py:108)
+// Also writes a0p[m][0..15] = [audio_0 (h values) | 1 | 0 ...]: the operand of the first WN layer, whose dilated conv is
+// composed with the start conv at load time (the constant 1 carries the start bias through the zero padding).
 __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __restrict__ w,
-                                const float* __restrict__ b, float* __restrict__ x, long long M, int h) {
+                                const float* __restrict__ b, float* __restrict__ x, float* __restrict__ a0p,
+                                long long M, int h) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of channels
     if (idx >= M * (C / 4)) return;
     const long long m = idx / (C / 4);
     const int c = (int)(idx % (C / 4)) * 4;
+    if (c < 16) {                                       // 4 threads of the row write the 16-float a0p row
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c + j;
+            v[j] = col < h ? audio[m * 8 + col] : (col == h ? 1.f : 0.f);
+        }
+        *reinterpret_cast<f32x4*>(a0p + m * 16 + c) = v;
+    }
     f32x4 acc = *reinterpret_cast<const f32x4*>(b + c);
     // the reference accumulates the dot product first and adds the bias last (Conv1D = conv + bias)
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -224,8 +237,8 @@ void waveglow_free(tts_hip_engine* e) {
     e->wg.spect.release();
     e->wg.x.release();
     e->wg.acts.release();
-    e->wg.skip.release();
     e->wg.audio.release();
+    e->wg.a0p.release();
     e->wg.io_mel.release();
     e->wg.io_z.release();
     e->wg.io_out.release();
@@ -297,14 +310,39 @@ int waveglow_finalize(tts_hip_engine* e) {
         for (int i = 0; i < 8; ++i) {
             WgLayerDev& ly = fl.layer[i];
             const std::string si = std::to_string(i);
-            WGCHK(dev_alloc(e, (size_t)2 * C * KIN, &ly.in_Bt, wg.allocs, false));
+            const int kin = i == 0 ? KIN0 : KIN, kconv = i == 0 ? 48 : 3 * C;
+            WGCHK(dev_alloc(e, (size_t)2 * C * kin, &ly.in_Bt, wg.allocs, false));
             WGCHK(need(p + "/in_conv-" + si + "/kernel", {3, C, 2 * C}, &t));
-            WGCHK(put(stage, t));
-            WGCHK(pack_bt(e, stage.f(), 3 * C, 2 * C, ly.in_Bt, 2 * C, KIN, 0, 1, WN_TAPS, TTS_WN_BK));
+            if (i == 0) {
+                // compose with the start conv (waveglow_arch.py:108): rows j < h: sum_c W_start[j][c] * W_in[tap][c][n];
+                // row h: sum_c b_start[c] * W_in[tap][c][n]; rows > h: 0.  Laid out [3 taps][16][1024] for pack_bt.
+                const HostTensor *ws, *bs;
+                WGCHK(need(p + "/start_conv/kernel", {1, n_half, C}, &ws));
+                WGCHK(need(p + "/start_conv/bias", {C}, &bs));
+                std::vector<float> comp((size_t)3 * 16 * 2 * C, 0.f);
+                std::vector<double> rowacc(2 * C);
+                for (int tap = 0; tap < 3; ++tap)
+                    for (int j = 0; j <= n_half; ++j) {
+                        for (int n = 0; n < 2 * C; ++n) rowacc[n] = 0.0;
+                        for (int c = 0; c < C; ++c) {
+                            const double sv = j < n_half ? (double)ws->data[(size_t)j * C + c] : (double)bs->data[c];
+                            const float* wr = t->data.data() + ((size_t)tap * C + c) * 2 * C;
+                            for (int n = 0; n < 2 * C; ++n) rowacc[n] += sv * (double)wr[n];
+                        }
+                        float* dst = comp.data() + ((size_t)tap * 16 + j) * 2 * C;
+                        for (int n = 0; n < 2 * C; ++n) dst[n] = (float)rowacc[n];
+                    }
+                HIPCHK(e, hipMemcpyAsync(stage.p, comp.data(), comp.size() * 4, hipMemcpyHostToDevice, e->stream));
+                HIPCHK(e, hipStreamSynchronize(e->stream));
+                WGCHK(pack_bt(e, stage.f(), 48, 2 * C, ly.in_Bt, 2 * C, kin, 0, 1));   // K order tap*16 + j: one 16-chunk per tap
+            } else {
+                WGCHK(put(stage, t));
+                WGCHK(pack_bt(e, stage.f(), 3 * C, 2 * C, ly.in_Bt, 2 * C, kin, 0, 1, WN_TAPS, TTS_WN_BK));
+            }
             HIPCHK(e, hipStreamSynchronize(e->stream));
             WGCHK(need(p + "/cond_layer-" + si + "/kernel", {1, NCOND, 2 * C}, &t));
             WGCHK(put(stage, t));
-            WGCHK(pack_bt(e, stage.f(), NCOND, 2 * C, ly.in_Bt, 2 * C, KIN, 3 * C, 1));
+            WGCHK(pack_bt(e, stage.f(), NCOND, 2 * C, ly.in_Bt, 2 * C, kin, kconv, 1));
             HIPCHK(e, hipStreamSynchronize(e->stream));
             WGCHK(need(p + "/in_conv-" + si + "/bias", {2 * C}, &t));
             WGCHK(need(p + "/cond_layer-" + si + "/bias", {2 * C}, &t2));
@@ -410,6 +448,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
     HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));      // activations of the 8 layers of one flow
     HIPCHK(e, wg.audio.ensure((size_t)M * 8 * 4));
+    HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
     hipStream_t st = e->stream;
 
     // ---- upsample + regroup: 32 phase GEMMs [B*T, 4*96] x [384, 640] -> spect rows t*32 + rr
@@ -447,7 +486,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         {
             const long long n4 = M * (C / 4);
             hipLaunchKernelGGL(wn_start_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, wg.audio.f(),
-                               fl.start_w, fl.start_b, wg.x.f(), M, h);
+                               fl.start_w, fl.start_b, wg.x.f(), wg.a0p.f(), M, h);
             HIPCHK(e, hipGetLastError());
         }
         for (int i = 0; i < 8; ++i) {
@@ -458,20 +497,29 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.N = 2 * C;
             g.L = L;
             g.nseg = 4;
-            g.seg[0] = ASeg{wg.x.f(), C, -d, C, C};
-            g.seg[1] = ASeg{wg.x.f(), C, 0, C, C};
-            g.seg[2] = ASeg{wg.x.f(), C, d, C, C};
+            if (i == 0) {
+                // first layer: conv(start(a0)) composed at load time -> K = 3 taps x 16 (h + 1 used) + 640 instead of 2176
+                g.seg[0] = ASeg{wg.a0p.f(), 16, -d, 16, 16};
+                g.seg[1] = ASeg{wg.a0p.f(), 16, 0, 16, 16};
+                g.seg[2] = ASeg{wg.a0p.f(), 16, d, 16, 16};
+                g.ldb = KIN0;
+            } else {
+                g.seg[0] = ASeg{wg.x.f(), C, -d, C, C};
+                g.seg[1] = ASeg{wg.x.f(), C, 0, C, C};
+                g.seg[2] = ASeg{wg.x.f(), C, d, C, C};
+                g.ldb = KIN;
+            }
             g.seg[3] = ASeg{wg.spect.f(), NCOND, 0, NCOND, NCOND};
             g.Bt = ly.in_Bt;
-            g.ldb = KIN;
             g.bias = ly.in_bias;
             g.mode = EPI_GATE;
             float* acts_i = wg.acts.f() + (size_t)i * M * C;
             g.out0 = acts_i;
             g.ld0 = C;
             g.split = 2 * C;
-            timing_begin(e, 0);
-            HIPCHK(e, gemm_wn_in(g, st));
+            timing_begin(e, i == 0 ? 3 : 0);
+            if (i == 0) HIPCHK(e, gemm_wn_in0(g, st));
+            else HIPCHK(e, gemm_wn_in(g, st));
             timing_end(e);
 
             if (i < 7) {                 // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
