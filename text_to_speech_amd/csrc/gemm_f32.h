@@ -462,7 +462,11 @@ constexpr int WN_TAPS = 3;
 inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 // first layer of a flow (start conv composed into the taps: K = 48 + 640); own TAG so profiles list it separately
 inline hipError_t gemm_wn_in0(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
-inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
+#ifndef TTS_WN_RES_RT
+#define TTS_WN_RES_RT 1   // residual GEMM (N = 512): 128-row tiles -> 6400 blocks, fills the 512 block slots more evenly
+#define TTS_WN_RES_OCC 3
+#endif
+inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RES_RT, 4, TTS_WN_BK, TTS_WN_RES_OCC, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
 inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1, 32, 1, TAG_GENERIC>(g, bz, s); }
 
 }  // namespace ttsgemm
