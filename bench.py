@@ -33,9 +33,13 @@ BATCH, FRAMES = 8, 800                 # BASELINE.json configs[1]
 SAMPLE_RATE = 22050
 
 
-def wn_in_layer_flops(M: int) -> float:
-    """Algorithmic FLOPs of one WN in-layer GEMM launch: dilated k3 conv 512->1024 + cond 1x1 640->1024 over M positions."""
-    return 2.0 * M * (3 * 512 + 640) * 1024
+K_EXECUTED = 3 * 512 + 4 * 80      # dilated k3 conv taps + conditioning folded onto 4 mel frames
+K_REFERENCE = 3 * 512 + 640        # the reference formulation: taps + 640-channel upsampled spectrogram
+
+
+def wn_in_layer_flops(M: int, k: int = K_EXECUTED) -> float:
+    """FLOPs of one WN in-layer GEMM launch over M positions (N = 1024 gate pre-activations)."""
+    return 2.0 * M * k * 1024
 
 
 def pmc_traffic_bytes(B, T):
@@ -190,10 +194,13 @@ def main():
         if launches:
             achieved = wn_in_layer_flops(M) / (avg_us * 1e-6) / 1e12
             roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic_bytes(B, T),
+                        'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+                        'flops_per_launch': wn_in_layer_flops(M),
+                        'reference_formulation_tflops': wn_in_layer_flops(M, K_REFERENCE) / (avg_us * 1e-6) / 1e12,
+                        'traffic': pmc_traffic_bytes(B, T),
                         'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
-                        'algorithmic_bytes': (M * (512 + 640 + 512) + 1024 * 2176) * 4.0,
-                        'kernel': 'gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow)', 'launches_timed': launches,
+                        'algorithmic_bytes': (M * (512 + 512) + B * T * 80 + 1024 * (1536 + 32 * 320)) * 4.0,
+                        'kernel': 'gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; K = 1536 taps + 320 folded conditioning)', 'launches_timed': launches,
                         'avg_launch_us': avg_us}
         cpu = None
         if args.cpu_frames > 0:

@@ -16,7 +16,7 @@ eng.kernel_timing(True)
 import time; t0 = time.perf_counter()
 for _ in range(2): eng.waveglow_infer(mel, z=z)
 dt = (time.perf_counter() - t0) / 2
-for kind, name, flops in ((0, 'in-layer K=2176', 2.0*B*T*32*2176*1024), (3, 'in-layer-0 K=688', 2.0*B*T*32*688*1024), (1, 'residual N=512', 2.0*B*T*32*512*512)):
+for kind, name, flops in ((0, 'in-layer K=1856', 2.0*B*T*32*1856*1024), (3, 'in-layer-0 K=368', 2.0*B*T*32*368*1024), (1, 'residual N=512', 2.0*B*T*32*512*512)):
     us, n = eng.kernel_time_us(kind)
     print(f'{name:18s} {n:4d} launches  avg {us:8.1f} us  {flops/us/1e6:6.1f} TFLOP/s')
 print(f'step {dt*1e3:.1f} ms')

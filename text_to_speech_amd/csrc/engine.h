@@ -43,8 +43,9 @@ struct DevBuf {
 
 // ---------------------------------------------------------------- WaveGlow (fixed reference geometry)
 struct WgLayerDev {
-    float* in_Bt = nullptr;     // [1024 (tanh/sigmoid interleaved per 128-tile)][2176 = 3*512 taps + 640 cond]
-    float* in_bias = nullptr;   // [1024] in_conv bias + cond bias, same row order
+    float* in_Bt = nullptr;     // [1024 (tanh/sigmoid interleaved per 128-tile)][3*512 taps] (first layer of a flow: [3*16])
+    float* cond_Bt = nullptr;   // [32 phases][1024][320] conditioning conv folded with the upsampling kernel
+    float* in_bias = nullptr;   // [1024] in_conv bias + cond bias (+ upsampling bias pushed through), same row order
     float* rs_Bt = nullptr;     // [512][512] residual half of res_skip (layers 0..6)
     float* rs_bias = nullptr;   // [512]
     int rs_n = 0;
@@ -60,11 +61,9 @@ struct WgFlowDev {
 };
 struct WaveGlowDev {
     bool ready = false;
-    float* up_Bt = nullptr;     // [32][640][384]
-    float* up_bias = nullptr;   // [640]
     WgFlowDev flow[12];
     std::vector<void*> allocs;
-    DevBuf spect, x, acts, audio, a0p, io_mel, io_z, io_out;
+    DevBuf x, acts, audio, a0p, io_mel, io_z, io_out;
 };
 
 // ---------------------------------------------------------------- Tacotron2

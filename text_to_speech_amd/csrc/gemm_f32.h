@@ -23,14 +23,21 @@ namespace ttsgemm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MAX_SEG = 5;
+constexpr int MAX_SEG = 8;
 
+// Row addressing of a segment.  With GemmArgs::phase_rows > 0 the M axis is "phase-major": row m = p * phase_rows + f
+// (p = one of 32 sample-group phases inside a mel frame, f = frame row), which keeps every conv tap a constant row
+// shift per block while making the phase block-uniform (needed for the per-phase conditioning weights).
+enum { SEG_ROWS = 0,        // operand row = m + shift
+       SEG_PHASE_TAP = 1,   // shift counts sample groups: phase' = (p + shift) mod 32, frame carry = floor((p + shift) / 32)
+       SEG_FRAME = 2 };     // operand row = f + shift (same operand for every phase, e.g. the mel frames)
 struct ASeg {
     const float* ptr;   // row m of the operand lives at ptr + (m + shift) * ld
     long long ld;       // row stride in floats
     int shift;          // row shift inside a sequence of L rows; rows shifted outside [0, L) read as zero
     int k;              // valid K extent of this segment (multiple of 4)
-    int kpad;           // K extent in Bt (multiple of 32, zero padded)
+    int kpad;           // K extent in Bt (multiple of BK, zero padded)
+    int kind;           // SEG_ROWS / SEG_PHASE_TAP / SEG_FRAME
 };
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
@@ -47,6 +54,12 @@ struct GemmArgs {
     long long strideBz;
     const float* bias;              // [N] or null
     long long strideBiasZ;
+    // ---- phase-major mode (0 = off)
+    int phase_rows;                 // rows per phase block (multiple of the M tile); M = 32 * phase_rows
+    int frames;                     // real frame rows per phase block (rows f >= frames are padding)
+    const float* Bt2;               // optional second weight matrix for the sequential segments [phase][N][ldb2]
+    long long ldb2;
+    long long strideB2p;            // per-phase stride of Bt2 (0: shared)
     // ---- epilogue
     int mode;                       // EPI_LINEAR / EPI_GATE
     int act;
@@ -74,6 +87,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);
+}
+// Same, for a base pointer that is wave-uniform but selected at run time (e.g. one of two weight matrices): rebuilding
+// the descriptor from readfirstlane'd halves keeps it in SGPRs; a select between two descriptors is lowered to a
+// VGPR/scratch copy plus a waterfall loop around every buffer op (cdna_hip_programming.md T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const float* base) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, OOB, 0x00020000);
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
@@ -172,12 +194,30 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     }
 
     // ---- operand addressing
+    const bool PH = g.phase_rows > 0;
+    const int ph = PH ? m0 / g.phase_rows : 0;          // block-uniform phase
+    const int f0 = PH ? m0 - ph * g.phase_rows : m0;    // first frame row of the tile
     int a_l[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + p * RPP + lrow;
-        a_l[p] = m < g.M ? m % g.L : -0x40000000;      // rows past M never pass the [0, L) test below
+        const int fr = f0 + p * RPP + lrow;
+        const bool ok = PH ? fr < g.frames : fr < g.M;
+        a_l[p] = ok ? fr % g.L : -0x40000000;           // padding rows never pass the [0, L) test below
     }
+    // (absolute operand row of the tile's first row, shift used for the sequence-bounds test) of a segment
+    auto seg_row = [&](const ASeg& sg, long long& abs_row, int& vshift) {
+        if (sg.kind == SEG_PHASE_TAP) {
+            const int ps = ph + sg.shift;
+            vshift = ps >> 5;                            // frame carry (arithmetic shift: floor)
+            abs_row = (long long)(ps & 31) * g.phase_rows + f0 + vshift;
+        } else if (sg.kind == SEG_FRAME) {
+            vshift = sg.shift;
+            abs_row = (long long)f0 + sg.shift;
+        } else {
+            vshift = sg.shift;
+            abs_row = (long long)m0 + sg.shift;
+        }
+    };
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.Bt + z * g.strideBz + (long long)n0 * g.ldb);
     unsigned b_off[PB];
 #pragma unroll
@@ -186,27 +226,32 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
 
     // tile iterator (wave-uniform) over the sequential segments [NI, nseg): current segment parameters live in
     // registers, refreshed only at a crossing
-    int s_cur = NI, kc_cur = 0, kglob = 0;
+    int s_cur = NI, kc_cur = 0, kglob = 0, kglob2 = 0;
     int seg_k = 0, seg_kpad = 0;
     __amdgpu_buffer_rsrc_t rsA;
     unsigned a_off[PA];
-    auto seg_rsrc = [&](const ASeg& sg) {
-        return make_rsrc(sg.ptr + z * g.strideAz + ((long long)m0 + sg.shift) * sg.ld);
-    };
-    auto seg_offsets = [&](const ASeg& sg, unsigned (&off)[PA]) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int l2 = a_l[p] + sg.shift;
-            off[p] = (l2 >= 0 && l2 < g.L) ? (unsigned)(((p * RPP + lrow) * (int)sg.ld + c4) * 4) : OOB;
-        }
-    };
     auto enter_segment = [&]() {
         const ASeg sg = g.seg[s_cur];
         seg_k = sg.k;
         seg_kpad = sg.kpad;
-        rsA = seg_rsrc(sg);
-        seg_offsets(sg, a_off);
+        long long abs_row;
+        int vshift;
+        seg_row(sg, abs_row, vshift);
+        rsA = make_rsrc(sg.ptr + z * g.strideAz + abs_row * sg.ld);
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int l2 = a_l[p] + vshift;
+            a_off[p] = (l2 >= 0 && l2 < g.L) ? (unsigned)(((p * RPP + lrow) * (int)sg.ld + c4) * 4) : OOB;
+        }
     };
+    // second weight matrix (per-phase) for the sequential segments
+    const bool B2 = g.Bt2 != nullptr;
+    const float* const bbase1 = g.Bt + z * g.strideBz + (long long)n0 * g.ldb;
+    const float* const bbase2 = (B2 ? g.Bt2 : g.Bt) + (long long)ph * g.strideB2p + (long long)n0 * g.ldb2;
+    unsigned b_off2[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+        b_off2[p] = (n0 + p * RPP + lrow < g.N) ? (unsigned)(((p * RPP + lrow) * (int)g.ldb2 + c4) * 4) : OOB;
 
     // ---- tile fetch: the same address generation feeds either register stages (PIPE_REG) or LDS-DMA (PIPE_DMA);
     // `emit(isA, p, rsrc, voffset)` is the sink.
@@ -218,28 +263,44 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     // byte delta and one validity bit per staged row change.
     static_assert(NI <= 4, "NI");
     const ASeg sg0 = g.seg[0];
-    const int sh0 = sg0.shift, sh1 = NI > 1 ? g.seg[NI > 1 ? 1 : 0].shift : sh0;
-    const int sh2 = NI > 2 ? g.seg[NI > 2 ? 2 : 0].shift : sh0, sh3 = NI > 3 ? g.seg[NI > 3 ? 3 : 0].shift : sh0;
-    auto shift_of = [&](int s) { return s == 0 ? sh0 : s == 1 ? sh1 : s == 2 ? sh2 : sh3; };
-    int min_shift = sh0;
-#pragma unroll
-    for (int s = 1; s < NI; ++s) min_shift = shift_of(s) < min_shift ? shift_of(s) : min_shift;
-    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(sg0.ptr + z * g.strideAz + ((long long)m0 + min_shift) * sg0.ld);
+    // per interleaved segment: byte offset of its tile base from the smallest one (32-bit: the operand spans < 2 GiB,
+    // checked at launch) and the validity bits of the staged rows.  Only these survive into the K loop.
+    unsigned dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0;
+    __amdgpu_buffer_rsrc_t rsI = rsB;
     unsigned baseI[PA], vmaskI[PA];
+    {
+        long long ab0 = 0, ab1 = 0, ab2 = 0, ab3 = 0;
+        int vs0 = 0, vs1 = 0, vs2 = 0, vs3 = 0;
+        if (NI > 0) seg_row(g.seg[0], ab0, vs0);
+        if (NI > 1) seg_row(g.seg[NI > 1 ? 1 : 0], ab1, vs1); else ab1 = ab0;
+        if (NI > 2) seg_row(g.seg[NI > 2 ? 2 : 0], ab2, vs2); else ab2 = ab0;
+        if (NI > 3) seg_row(g.seg[NI > 3 ? 3 : 0], ab3, vs3); else ab3 = ab0;
+        long long row0 = ab0;
+        row0 = ab1 < row0 ? ab1 : row0;
+        row0 = ab2 < row0 ? ab2 : row0;
+        row0 = ab3 < row0 ? ab3 : row0;
+        if (NI > 0) rsI = make_rsrc(sg0.ptr + z * g.strideAz + row0 * sg0.ld);
+        const int ld4 = (int)sg0.ld * 4;
+        dl0 = (unsigned)((int)(ab0 - row0) * ld4);
+        dl1 = (unsigned)((int)(ab1 - row0) * ld4);
+        dl2 = (unsigned)((int)(ab2 - row0) * ld4);
+        dl3 = (unsigned)((int)(ab3 - row0) * ld4);
+        auto vs_of = [&](int s2) { return s2 == 0 ? vs0 : s2 == 1 ? vs1 : s2 == 2 ? vs2 : vs3; };
 #pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        baseI[p] = (unsigned)(((p * RPP + lrow) * (int)sg0.ld + c4) * 4);
-        unsigned vm = 0;
+        for (int p = 0; p < PA; ++p) {
+            baseI[p] = (unsigned)(((p * RPP + lrow) * (int)sg0.ld + c4) * 4);
+            unsigned vm = 0;
 #pragma unroll
-        for (int s = 0; s < NI; ++s) {
-            const int l2 = a_l[p] + shift_of(s);
-            vm |= (l2 >= 0 && l2 < g.L) ? (1u << s) : 0u;
+            for (int s = 0; s < NI; ++s) {
+                const int l2 = a_l[p] + vs_of(s);
+                vm |= (l2 >= 0 && l2 < g.L) ? (1u << s) : 0u;
+            }
+            vmaskI[p] = vm;
         }
-        vmaskI[p] = vm;
     }
+    auto delta_of = [&](int s) { return s == 0 ? dl0 : s == 1 ? dl1 : s == 2 ? dl2 : dl3; };
     const int kI = sg0.k;
     const int nI = NI > 0 ? NI * (sg0.kpad / BK) : 0;
-    const int ldb4 = (int)sg0.ld * 4;
     int si = 0, kci = 0;                             // (segment, chunk) of the next interleaved tile to load
     const int nAll = nI + nSeq;
     int t_load = 0;                                  // index of the next tile to fetch
@@ -247,7 +308,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     auto fetch_next = [&](auto&& emit) {             // issues the loads of tile `t_load` (if any) and advances
         if (t_load < nAll) {
             if (NI > 0 && t_load < nI) {
-                const unsigned delta = (unsigned)((shift_of(si) - min_shift) * ldb4 + kci * BK * 4);
+                const unsigned delta = delta_of(si) + (unsigned)(kci * BK * 4);
                 const bool kok = kci * BK + c4 < kI;
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
@@ -268,10 +329,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
                     if (++s_cur < g.nseg) enter_segment();
                 }
             }
-            const unsigned kg = (unsigned)(kglob * 4);
+            // weight tile: the sequential segments may use their own (per-phase) matrix Bt2
+            const bool use2 = B2 && !(NI > 0 && t_load < nI);
+            const __amdgpu_buffer_rsrc_t rsW = make_rsrc_uniform(use2 ? bbase2 : bbase1);
+            const unsigned kg = (unsigned)((use2 ? kglob2 : kglob) * 4);
 #pragma unroll
-            for (int p = 0; p < PB; ++p) emit(false, p, rsB, b_off[p] + kg);
-            kglob += BK;
+            for (int p = 0; p < PB; ++p) emit(false, p, rsW, (use2 ? b_off2[p] : b_off[p]) + kg);
+            if (use2) kglob2 += BK;
+            else kglob += BK;
         }
         ++t_load;
     };
@@ -424,6 +489,11 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
     const int numMt8 = (numMt + 7) / 8 * 8;
     const size_t lds = (size_t)NBUF * (BM + BN) * LDSK * sizeof(float);
     if (g.split < g.N && g.split % BN != 0) return hipErrorInvalidValue;     // output side must be uniform per block
+    if (g.phase_rows > 0) {
+        // tiles must not straddle phases; the interleaved-tap descriptor spans at most the whole operand (31-bit offsets)
+        if (g.phase_rows % BM != 0 || g.M != 32 * g.phase_rows) return hipErrorInvalidValue;
+        if (32.0 * g.phase_rows * (double)g.seg[0].ld * 4.0 >= 2147483648.0 - 65536.0) return hipErrorInvalidValue;
+    }
     if (NI > 0) {
         if (g.nseg < NI) return hipErrorInvalidValue;
         for (int i = 1; i < NI; ++i)

@@ -3,13 +3,24 @@
 // Replaces /root/reference/architectures/waveglow_arch.py:244-306 (WaveGlow.infer), :105-141 (WaveglowBlock.call) and
 // architectures/layers/invertible_conv.py:41-51 (Invertible1x1Conv reverse).
 //
-// HBM layout (all float32, channels-last, M = B * L positions, L = T * 32 groups of 8 samples):
-//   spect [M][640]   upsampled + regrouped conditioning (channel = mel * 8 + g), written once per call
-//   x     [M][512]   WN residual stream, updated in place by the residual GEMM epilogue
-//   acts  [8][M][512] gated activations tanh * sigmoid of the 8 layers of the current flow (in-layer GEMM epilogue)
-//   audio [M][8]     current flow state in the first n_rem columns; after the last flow it IS the output [B][L*8]
-// Per flow: start (VALU) -> 8 x { in-layer implicit GEMM (K = 3 taps * 512 + 640 cond, N = 1024, gate epilogue),
+// HBM layout (all float32, channels-last).  Positions are kept PHASE-MAJOR inside the engine: a position is a group of
+// 8 samples, l = 32 * t + p (t = mel frame, p = phase 0..31); row m' = p * PR + f with f = b * T + t the global frame
+// index and PR = B*T rounded up to the 256-row tile.  A conv tap l +- d then stays a constant row shift per tile
+// (phase' = (p +- d) mod 32, frame carry = floor((p +- d) / 32)) and the phase is uniform per tile, which is what the
+// low-rank conditioning below needs.  M' = 32 * PR rows:
+//   x     [M'][512]   WN residual stream, updated in place by the residual GEMM epilogue
+//   acts  [8][M'][512] gated activations tanh * sigmoid of the 8 layers of the current flow (in-layer GEMM epilogue)
+//   a0p   [M'][16]    [audio_0 | 1 | 0..]: operand of the first layer of a flow (start conv composed into its taps)
+//   audio [M'][8]     current flow state in the first n_rem columns; the last flow writes the caller's [B][L*8] directly
+// Per flow: start (VALU) -> 8 x { in-layer implicit GEMM (K = 3 taps * 512 + 4 * 80 mel, N = 1024, gate epilogue),
 // residual GEMM (K = 512, N = 512; not for the last layer) } -> folded skip/end + affine inverse + inverse 1x1 conv.
+//
+// Conditioning folding (exact algebra, load time): the reference upsamples the mel with a transposed conv
+// (k 1024, stride 256), regroups 8 samples x 80 channels into 640 channels and applies a 640 -> 1024 1x1 conv per layer
+// (waveglow_arch.py:245-253,125).  A group at phase p only sees mel frames t-3..t, so
+//     cond_i[l] = V_{i,p} @ [mel[t], mel[t-1], mel[t-2], mel[t-3]] + const,   V_{i,p} = W_cond_i @ U_p  (1024 x 320),
+// i.e. K = 320 instead of 640 (-14.7 % of the in-layer FLOPs), no upsampling pass and no [M][640] spectrogram in HBM.
+// The price is 32 per-phase copies of the conditioning weights (42 MB per layer, 4 GB in all), streamed once per launch.
 //
 // Skip path folding (exact algebra, done once at load time): the reference sums the skip halves of the 8 res_skip convs
 // and feeds the sum to the `end` 1x1 conv (waveglow_arch.py:129-141).  Both are linear, so
@@ -21,16 +32,19 @@
 #include "gemm_f32.h"
 
 #include <cmath>
+#include <cstdlib>
 
 using namespace ttsgemm;
 
 namespace {
 
 constexpr int C = 512;        // n_channels
-constexpr int NCOND = 640;    // n_mel * n_group
-constexpr int KIN = 3 * C + NCOND;
-constexpr int KIN0 = 3 * 16 + NCOND;    // first layer of a flow: taps act on [audio_0 | 1] (16-float rows)
-constexpr int UPK = 4 * 96;   // upsampling K: 4 taps x (80 padded to 96)
+constexpr int NCOND = 640;    // n_mel * n_group (reference layout of the conditioning input)
+constexpr int KCONV = 3 * C;  // taps part of the in-layer K
+constexpr int KCONV0 = 3 * 16;// first layer of a flow: taps act on [audio_0 | 1] (16-float rows)
+constexpr int KMEL = 4 * 80;  // folded conditioning: 4 mel frames x 80 channels
+constexpr int NPH = 32;       // phases (sample groups per mel frame)
+constexpr int MTILE = 256;    // phase blocks are padded to the largest M tile
 
 // dst[n][koff + k] = src[k * src_ld + perm(n)]  for k < K   (Keras [K][N] kernel slice -> Bt rows)
 // perm: 0 identity; 1 WN gate interleave (per 128-row tile: 64 tanh channels then their 64 sigmoid partners)
@@ -66,38 +80,41 @@ __global__ void pack_bias_kernel(const float* __restrict__ a, const float* __res
     dst[n] = a[sn] + (b ? b[sn] : 0.f);
 }
 
-// Upsampling kernel [1024][80 out][80 in] -> Bt[rr][n = o*8 + g][q*96 + i] = W[(rr*8 + g) + 256 q][o][i]
-__global__ void pack_upsample_kernel(const float* __restrict__ w, float* __restrict__ dst) {
+// Transposed-conv kernel [1024][80 out][80 in] -> UT[p][q*80 + j][c*8 + g] = W[(p*8 + g) + 256 q][c][j]
+// (the "Bt" operand of V_{i,p} = WcT_i @ U_p: row = mel-window input (q, j), K = regrouped channel c*8 + g)
+__global__ void pack_ut_kernel(const float* __restrict__ w, float* __restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = 32ll * 640 * UPK;
+    const long long total = (long long)NPH * KMEL * NCOND;
     if (idx >= total) return;
-    const int kk = (int)(idx % UPK);
-    const int n = (int)((idx / UPK) % 640);
-    const int rr = (int)(idx / ((long long)UPK * 640));
-    const int q = kk / 96, i = kk % 96;
-    const int o = n >> 3, gidx = n & 7;
-    float v = 0.f;
-    if (i < 80) v = w[((long long)(rr * 8 + gidx + 256 * q) * 80 + o) * 80 + i];
-    dst[idx] = v;
+    const int k = (int)(idx % NCOND);
+    const int r = (int)((idx / NCOND) % KMEL);
+    const int p = (int)(idx / ((long long)NCOND * KMEL));
+    const int c = k >> 3, gidx = k & 7, q = r / 80, j = r % 80;
+    dst[idx] = w[((long long)(p * 8 + gidx + 256 * q) * 80 + c) * 80 + j];
 }
 
-__global__ void expand_up_bias_kernel(const float* __restrict__ b, float* __restrict__ dst) {
+// bias[n] += sum_k WcT[n][k] * b_up[k >> 3]     (upsampling bias pushed through the conditioning conv)
+__global__ void cond_bias_kernel(const float* __restrict__ wct, const float* __restrict__ b_up, float* __restrict__ bias) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < 640) dst[n] = b[n >> 3];
+    if (n >= 2 * C) return;
+    float acc = 0.f;
+    for (int k = 0; k < NCOND; ++k) acc = fmaf(wct[(long long)n * NCOND + k], b_up[k >> 3], acc);
+    bias[n] += acc;
 }
 
-// audio[m][0..3] = sigma * z[m][0..3]  (z null => zeros)
-__global__ void init_audio_kernel(const float* __restrict__ z, float sigma, float* __restrict__ audio, long long M) {
-    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+// audio[m'][0..3] = sigma * z[natural m][0..3]  (z null => zeros); m' = p * PR + f  <->  m = f * 32 + p
+__global__ void init_audio_kernel(const float* __restrict__ z, float sigma, float* __restrict__ audio, int PR, int BT) {
+    const long long mp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (mp >= (long long)NPH * PR) return;
+    const int p = (int)(mp / PR), f = (int)(mp % PR);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (z) {
-        v = *reinterpret_cast<const f32x4*>(z + m * 8);
+    if (z && f < BT) {
+        v = *reinterpret_cast<const f32x4*>(z + ((long long)f * NPH + p) * 8);
         v *= sigma;
     }
-    *reinterpret_cast<f32x4*>(audio + m * 8) = v;
+    *reinterpret_cast<f32x4*>(audio + mp * 8) = v;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(audio + m * 8 + 4) = zero;
+    *reinterpret_cast<f32x4*>(audio + mp * 8 + 4) = zero;
 }
 
 // x[m][c] = sum_{j < h} audio[m][j] * w[j][c] + b[c]      (start 1x1 conv, waveglow_arch.py:108)
@@ -141,8 +158,9 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const float* __restric
                                                           const float* __restrict__ wfold,
                                                           const float* __restrict__ bfold,
                                                           const float* __restrict__ inv, float* __restrict__ audio_io,
-                                                          float* __restrict__ audio_out, const float* __restrict__ z,
-                                                          int zoff, int n_early, float sigma, long long M, int h) {
+                                                          float* __restrict__ audio_out, int out_natural,
+                                                          const float* __restrict__ z, int zoff, int n_early,
+                                                          float sigma, long long M, int h, int PR, int BT) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long m0 = wave * RPW;
@@ -195,7 +213,9 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const float* __restric
 #pragma unroll
     for (int o = 0; o < 8; ++o) out[o] = __shfl(mine, (lane & ~7) + o, 64);
     const long long m = m0 + (lane >> 3);
-    if ((lane & 7) == 0 && m < M) {
+    const int ph = (int)(m / PR), fr = (int)(m % PR);          // phase-major row -> (phase, frame)
+    const long long mnat = (long long)fr * NPH + ph;           // natural position index b * L + t * 32 + p
+    if ((lane & 7) == 0 && m < M && fr < BT) {
         float a[8], y[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = j < cch ? audio_io[m * 8 + j] : 0.f;
@@ -214,8 +234,8 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const float* __restric
             }
             res[c] = t;
         }
-        float* dst = audio_out + m * 8;
-        for (int j = 0; j < n_early; ++j) dst[j] = z ? sigma * z[m * 8 + zoff + j] : 0.f;
+        float* dst = audio_out + (out_natural ? mnat : m) * 8;
+        for (int j = 0; j < n_early; ++j) dst[j] = z ? sigma * z[mnat * 8 + zoff + j] : 0.f;
         for (int c = 0; c < cch; ++c) dst[n_early + c] = res[c];
     }
 }
@@ -234,7 +254,6 @@ int pack_bt(tts_hip_engine* e, const float* d_src, int K, int src_ld, float* dst
 void waveglow_free(tts_hip_engine* e) {
     for (void* p : e->wg.allocs) (void)hipFree(p);
     e->wg.allocs.clear();
-    e->wg.spect.release();
     e->wg.x.release();
     e->wg.acts.release();
     e->wg.audio.release();
@@ -257,10 +276,12 @@ int waveglow_finalize(tts_hip_engine* e) {
         return 0;
     };
     int rc;
-    // staging buffer for raw Keras-layout kernels (largest: upsample 1024*80*80 = 6.55 M floats)
-    DevBuf stage, stage2;
+    // staging buffers for raw Keras-layout kernels (largest: upsample 1024*80*80 = 6.55 M floats)
+    DevBuf stage, stage2, ut, wct;
     HIPCHK(e, stage.ensure((size_t)1024 * 80 * 80 * 4));
-    HIPCHK(e, stage2.ensure((size_t)1024 * 4 * 2));
+    HIPCHK(e, stage2.ensure((size_t)1024 * 4 * 2 + 1024));
+    HIPCHK(e, ut.ensure((size_t)NPH * KMEL * NCOND * 4));
+    HIPCHK(e, wct.ensure((size_t)2 * C * NCOND * 4));
     auto put = [&](DevBuf& b, const HostTensor* t) -> int {
         HIPCHK(e, hipMemcpyAsync(b.p, t->data.data(), t->numel() * 4, hipMemcpyHostToDevice, e->stream));
         return 0;
@@ -268,6 +289,8 @@ int waveglow_finalize(tts_hip_engine* e) {
     auto done = [&]() {
         stage.release();
         stage2.release();
+        ut.release();
+        wct.release();
     };
 #define WGCHK(x)          \
     if ((rc = (x))) {     \
@@ -276,20 +299,18 @@ int waveglow_finalize(tts_hip_engine* e) {
         return rc;        \
     }
     const HostTensor *t, *t2;
-    // ---- upsampling
+    // ---- transposed-conv upsampling kernel -> per-phase operand UT (only used to fold the conditioning convs below)
     WGCHK(need("waveglow/upsample/kernel", {1024, 80, 80}, &t));
-    WGCHK(dev_alloc(e, (size_t)32 * 640 * UPK, &wg.up_Bt, wg.allocs, false));
     WGCHK(put(stage, t));
     {
-        const long long total = 32ll * 640 * UPK;
-        hipLaunchKernelGGL(pack_upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
-                           stage.f(), wg.up_Bt);
+        const long long total = (long long)NPH * KMEL * NCOND;
+        hipLaunchKernelGGL(pack_ut_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, stage.f(),
+                           ut.f());
+        HIPCHK(e, hipGetLastError());
     }
     WGCHK(need("waveglow/upsample/bias", {80}, &t));
-    WGCHK(dev_alloc(e, 640, &wg.up_bias, wg.allocs, false));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    WGCHK(put(stage, t));
-    hipLaunchKernelGGL(expand_up_bias_kernel, dim3(3), dim3(256), 0, e->stream, stage.f(), wg.up_bias);
+    float* d_bup = stage2.f() + 4 * C;              // 80 floats behind the bias staging area
+    HIPCHK(e, hipMemcpyAsync(d_bup, t->data.data(), 80 * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
 
     // ---- flows
@@ -310,8 +331,8 @@ int waveglow_finalize(tts_hip_engine* e) {
         for (int i = 0; i < 8; ++i) {
             WgLayerDev& ly = fl.layer[i];
             const std::string si = std::to_string(i);
-            const int kin = i == 0 ? KIN0 : KIN, kconv = i == 0 ? 48 : 3 * C;
-            WGCHK(dev_alloc(e, (size_t)2 * C * kin, &ly.in_Bt, wg.allocs, false));
+            const int kconv = i == 0 ? KCONV0 : KCONV;
+            WGCHK(dev_alloc(e, (size_t)2 * C * kconv, &ly.in_Bt, wg.allocs, false));
             WGCHK(need(p + "/in_conv-" + si + "/kernel", {3, C, 2 * C}, &t));
             if (i == 0) {
                 // compose with the start conv (waveglow_arch.py:108): rows j < h: sum_c W_start[j][c] * W_in[tap][c][n];
@@ -334,16 +355,34 @@ int waveglow_finalize(tts_hip_engine* e) {
                     }
                 HIPCHK(e, hipMemcpyAsync(stage.p, comp.data(), comp.size() * 4, hipMemcpyHostToDevice, e->stream));
                 HIPCHK(e, hipStreamSynchronize(e->stream));
-                WGCHK(pack_bt(e, stage.f(), 48, 2 * C, ly.in_Bt, 2 * C, kin, 0, 1));   // K order tap*16 + j: one 16-chunk per tap
+                WGCHK(pack_bt(e, stage.f(), KCONV0, 2 * C, ly.in_Bt, 2 * C, kconv, 0, 1));   // K order tap*16 + j
             } else {
                 WGCHK(put(stage, t));
-                WGCHK(pack_bt(e, stage.f(), 3 * C, 2 * C, ly.in_Bt, 2 * C, kin, 0, 1, WN_TAPS, TTS_WN_BK));
+                WGCHK(pack_bt(e, stage.f(), 3 * C, 2 * C, ly.in_Bt, 2 * C, kconv, 0, 1, WN_TAPS, TTS_WN_BK));
             }
             HIPCHK(e, hipStreamSynchronize(e->stream));
+            // conditioning conv: WcT[n'][k] (gate-permuted rows), then V_{i,p} = WcT @ U_p for the 32 phases
             WGCHK(need(p + "/cond_layer-" + si + "/kernel", {1, NCOND, 2 * C}, &t));
             WGCHK(put(stage, t));
-            WGCHK(pack_bt(e, stage.f(), NCOND, 2 * C, ly.in_Bt, 2 * C, kin, kconv, 1));
-            HIPCHK(e, hipStreamSynchronize(e->stream));
+            WGCHK(pack_bt(e, stage.f(), NCOND, 2 * C, wct.f(), 2 * C, NCOND, 0, 1));
+            WGCHK(dev_alloc(e, (size_t)NPH * 2 * C * KMEL, &ly.cond_Bt, wg.allocs, false));
+            {
+                GemmArgs g{};
+                g.M = 2 * C;
+                g.N = KMEL;
+                g.L = 2 * C;
+                g.nseg = 1;
+                g.seg[0] = ASeg{wct.f(), NCOND, 0, NCOND, NCOND};
+                g.Bt = ut.f();
+                g.ldb = NCOND;
+                g.strideBz = (long long)KMEL * NCOND;
+                g.mode = EPI_LINEAR;
+                g.split = KMEL;
+                g.out0 = ly.cond_Bt;
+                g.ld0 = KMEL;
+                g.strideOutZ = (long long)2 * C * KMEL;
+                HIPCHK(e, gemm_small(g, NPH, e->stream));
+            }
             WGCHK(need(p + "/in_conv-" + si + "/bias", {2 * C}, &t));
             WGCHK(need(p + "/cond_layer-" + si + "/bias", {2 * C}, &t2));
             WGCHK(dev_alloc(e, 2 * C, &ly.in_bias, wg.allocs, false));
@@ -351,6 +390,8 @@ int waveglow_finalize(tts_hip_engine* e) {
             HIPCHK(e, hipMemcpyAsync(stage2.f() + 2 * C, t2->data.data(), 2 * C * 4, hipMemcpyHostToDevice, e->stream));
             hipLaunchKernelGGL(pack_bias_kernel, dim3(4), dim3(256), 0, e->stream, stage2.f(), stage2.f() + 2 * C,
                                ly.in_bias, 2 * C, 1);
+            hipLaunchKernelGGL(cond_bias_kernel, dim3(4), dim3(256), 0, e->stream, wct.f(), d_bup, ly.in_bias);
+            HIPCHK(e, hipGetLastError());
             HIPCHK(e, hipStreamSynchronize(e->stream));
             // res_skip conv: keep only the residual half as a GEMM operand (layers 0..6); the skip half is folded below
             const int rs_full = i < 7 ? 2 * C : C;
@@ -442,41 +483,19 @@ int waveglow_finalize(tts_hip_engine* e) {
 
 int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio) {
     WaveGlowDev& wg = e->wg;
-    const int L = T * 32;
-    const long long M = (long long)B * L;
-    HIPCHK(e, wg.spect.ensure((size_t)M * NCOND * 4));
+    const int BT = B * T;                                        // frames
+    const int PR = (BT + MTILE - 1) / MTILE * MTILE;             // rows per phase block (padded to the M tile)
+    const long long M = (long long)NPH * PR;                     // phase-major rows (incl. padding)
+    if ((double)M * C * 4.0 >= 2147483648.0 - 65536.0)
+        return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: B*T = %d frames exceeds one call's limit (~32000)", BT);
     HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
-    HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));      // activations of the 8 layers of one flow
+    HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));          // activations of the 8 layers of one flow
     HIPCHK(e, wg.audio.ensure((size_t)M * 8 * 4));
     HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
     hipStream_t st = e->stream;
 
-    // ---- upsample + regroup: 32 phase GEMMs [B*T, 4*96] x [384, 640] -> spect rows t*32 + rr
-    {
-        GemmArgs g{};
-        g.M = B * T;
-        g.N = 640;
-        g.L = T;
-        g.nseg = 4;
-        for (int q = 0; q < 4; ++q) g.seg[q] = ASeg{d_mel, 80, -q, 80, 96};
-        g.strideAz = 0;
-        g.Bt = wg.up_Bt;
-        g.ldb = UPK;
-        g.strideBz = 640ll * UPK;
-        g.bias = wg.up_bias;
-        g.strideBiasZ = 0;
-        g.mode = EPI_LINEAR;
-        g.act = ACT_NONE;
-        g.split = 640;
-        g.out0 = wg.spect.f();
-        g.ld0 = 32ll * NCOND;
-        g.acc0 = 0;
-        g.out1 = nullptr;
-        g.strideOutZ = NCOND;
-        HIPCHK(e, gemm_big(g, 32, st));
-    }
     const unsigned mb = (unsigned)((M + 255) / 256);
-    hipLaunchKernelGGL(init_audio_kernel, dim3(mb), dim3(256), 0, st, d_z, sigma, wg.audio.f(), M);
+    hipLaunchKernelGGL(init_audio_kernel, dim3(mb), dim3(256), 0, st, d_z, sigma, wg.audio.f(), PR, BT);
     HIPCHK(e, hipGetLastError());
 
     int zoff = 4;
@@ -495,22 +514,24 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             GemmArgs g{};
             g.M = (int)M;
             g.N = 2 * C;
-            g.L = L;
-            g.nseg = 4;
+            g.L = T;                                   // sequence bounds are tested on the frame index inside a batch item
+            g.phase_rows = PR;
+            g.frames = BT;
+            g.nseg = 7;
             if (i == 0) {
-                // first layer: conv(start(a0)) composed at load time -> K = 3 taps x 16 (h + 1 used) + 640 instead of 2176
-                g.seg[0] = ASeg{wg.a0p.f(), 16, -d, 16, 16};
-                g.seg[1] = ASeg{wg.a0p.f(), 16, 0, 16, 16};
-                g.seg[2] = ASeg{wg.a0p.f(), 16, d, 16, 16};
-                g.ldb = KIN0;
+                // first layer: conv(start(a0)) composed at load time -> K = 3 taps x 16 (h + 1 used) instead of 3 x 512
+                for (int tap = 0; tap < 3; ++tap) g.seg[tap] = ASeg{wg.a0p.f(), 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP};
+                g.ldb = KCONV0;
             } else {
-                g.seg[0] = ASeg{wg.x.f(), C, -d, C, C};
-                g.seg[1] = ASeg{wg.x.f(), C, 0, C, C};
-                g.seg[2] = ASeg{wg.x.f(), C, d, C, C};
-                g.ldb = KIN;
+                for (int tap = 0; tap < 3; ++tap) g.seg[tap] = ASeg{wg.x.f(), C, (tap - 1) * d, C, C, SEG_PHASE_TAP};
+                g.ldb = KCONV;
             }
-            g.seg[3] = ASeg{wg.spect.f(), NCOND, 0, NCOND, NCOND};
+            // folded conditioning: mel frames t, t-1, t-2, t-3 against the per-phase weights V_{i,p}
+            for (int q = 0; q < 4; ++q) g.seg[3 + q] = ASeg{d_mel, 80, -q, 80, 80, SEG_FRAME};
             g.Bt = ly.in_Bt;
+            g.Bt2 = ly.cond_Bt;
+            g.ldb2 = KMEL;
+            g.strideB2p = (long long)2 * C * KMEL;
             g.bias = ly.in_bias;
             g.mode = EPI_GATE;
             float* acts_i = wg.acts.f() + (size_t)i * M * C;
@@ -547,8 +568,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         float* dst = (k == 0) ? d_audio : wg.audio.f();
         const long long waves = (M + RPW - 1) / RPW;
         hipLaunchKernelGGL(wn_end_fold_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, wg.acts.f(),
-                           (long long)M * C, fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, d_z, zoff, early ? 2 : 0,
-                           sigma, M, h);
+                           (long long)M * C, fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, k == 0 ? 1 : 0, d_z, zoff,
+                           early ? 2 : 0, sigma, M, h, PR, BT);
         HIPCHK(e, hipGetLastError());
         if (early) zoff += 2;
     }
