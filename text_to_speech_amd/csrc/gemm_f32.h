@@ -530,7 +530,10 @@ inline hipError_t gemm_big(const GemmArgs& g, int bz, hipStream_t s) { return la
 // WN in-layer GEMM: the three conv taps are interleaved in K (weights packed to match, see pack_bt_kernel)
 constexpr int WN_TAPS = 3;
 inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
-// first layer of a flow (start conv composed into the taps: K = 48 + 640); own TAG so profiles list it separately
+// 128-row-tile variants: used when padding the phase blocks to 256 rows would waste more work (e.g. batch 1)
+inline hipError_t gemm_wn_in_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_in0_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+// first layer of a flow (start conv composed into the taps: K = 48 + 320); own TAG so profiles list it separately
 inline hipError_t gemm_wn_in0(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 #ifndef TTS_WN_RES_RT
 #define TTS_WN_RES_RT 1   // residual GEMM (N = 512): 128-row tiles -> 6400 blocks, fills the 512 block slots more evenly

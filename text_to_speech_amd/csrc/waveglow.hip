@@ -44,7 +44,6 @@ constexpr int KCONV = 3 * C;  // taps part of the in-layer K
 constexpr int KCONV0 = 3 * 16;// first layer of a flow: taps act on [audio_0 | 1] (16-float rows)
 constexpr int KMEL = 4 * 80;  // folded conditioning: 4 mel frames x 80 channels
 constexpr int NPH = 32;       // phases (sample groups per mel frame)
-constexpr int MTILE = 256;    // phase blocks are padded to the largest M tile
 
 // dst[n][koff + k] = src[k * src_ld + perm(n)]  for k < K   (Keras [K][N] kernel slice -> Bt rows)
 // perm: 0 identity; 1 WN gate interleave (per 128-row tile: 64 tanh channels then their 64 sigmoid partners)
@@ -484,7 +483,10 @@ int waveglow_finalize(tts_hip_engine* e) {
 int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio) {
     WaveGlowDev& wg = e->wg;
     const int BT = B * T;                                        // frames
-    const int PR = (BT + MTILE - 1) / MTILE * MTILE;             // rows per phase block (padded to the M tile)
+    // rows per phase block, padded to the M tile: 256-row tiles unless 128-row tiles save at least 5 % of the rows
+    const int pr256 = (BT + 255) / 256 * 256, pr128 = (BT + 127) / 128 * 128;
+    const bool tile128 = pr128 * 1.05 < pr256;
+    const int PR = tile128 ? pr128 : pr256;
     const long long M = (long long)NPH * PR;                     // phase-major rows (incl. padding)
     if ((double)M * C * 4.0 >= 2147483648.0 - 65536.0)
         return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: B*T = %d frames exceeds one call's limit (~32000)", BT);
@@ -539,8 +541,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.ld0 = C;
             g.split = 2 * C;
             timing_begin(e, i == 0 ? 3 : 0);
-            if (i == 0) HIPCHK(e, gemm_wn_in0(g, st));
-            else HIPCHK(e, gemm_wn_in(g, st));
+            if (i == 0) HIPCHK(e, tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
+            else HIPCHK(e, tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
             timing_end(e);
 
             if (i < 7) {                 // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
