@@ -136,7 +136,7 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N')
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get('TTS_BENCH_FORCE_DIST') == '1'   # (env: exercise the RCCL path at N = 1)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)

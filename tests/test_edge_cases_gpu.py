@@ -158,3 +158,31 @@ def test_pipeline_batch_mixed_lengths(taco_cfg, wg_weights, wg_cfg):
     for b in range(4):
         assert audios[b].shape == (ref.lengths[b] * 256,)
         assert rms(audios[b] - ref_audio[b, :ref.lengths[b] * 256]) <= 1e-4
+
+
+def test_tts_and_stream_facade_on_the_engine(gpu_engine):
+    """models.tts.tts()/stream() call shapes (models/tts/__init__.py:62-101) on the real HIP engine.
+
+    Synthetic weights never fire the stop token, so every part runs to max_length = 6 x tokens (ratio 6 is inside the
+    reference's (2, 10) acceptance window: no retry), then is vocoded and concatenated."""
+    import queue
+    from text_to_speech_amd.runtime import HipRuntime
+    from text_to_speech_amd.tacotron2 import Tacotron2, tts, stream
+    from text_to_speech_amd.waveglow import WaveGlow
+    model = Tacotron2(HipRuntime('t', model='tacotron2', engine=gpu_engine, seed=0))
+    voc = WaveGlow(HipRuntime('w', model='waveglow', engine=gpu_engine, seed=0))
+    (text, res), = tts('Hello there. General test!', model=model, vocoder=voc, max_length=6., max_text_length=-2)
+    assert res['splitted'] == ['hello there.', 'general test!']
+    frames = [m.shape[0] for m in res['mel']]
+    assert frames == [6 * 12, 6 * 13]
+    assert res['audio'].shape == (sum(frames) * 256,) and np.isfinite(res['audio']).all() and res['rate'] == 22050
+    # windowed vocoding of a long mel through the same engine: seamless length, finite
+    long_audio = voc.infer(np.concatenate(res['mel'], 0), win_len=64, hop_len=-16)
+    assert long_audio.shape == (sum(frames) * 256,) and np.isfinite(long_audio).all()
+    q = queue.Queue()
+    for s in ('First sentence.', 'Second one.', None):
+        q.put(s)
+    got = []
+    stream(q, model=model, vocoder=voc, max_length=6., callbacks=[lambda r: got.append((r['text'], len(r['audio'])))])
+    assert [g[0] for g in got] == ['First sentence.', 'Second one.']
+    assert got[0][1] == 6 * 15 * 256 and got[1][1] == 6 * 11 * 256

@@ -1,0 +1,256 @@
+"""Import NVIDIA Tacotron2 / WaveGlow PyTorch checkpoints into the engine's tensor manifest (and a TTSW file).
+
+The reference's shipped models are NVIDIA's checkpoints converted to Keras (`architectures/tacotron2_arch.py:934-941`,
+`waveglow_arch.py:327-335` load them through torch.hub; `models/weights_converter.py:252-322` re-lays them out).  This
+module restates those layout rules so a `.pt` state dict can be used directly:
+
+  Linear            torch [out, in]            -> Dense kernel [in, out]
+  Conv1d            torch [out, in, k]         -> Conv1D kernel [k, in, out]
+  ConvTranspose1d   torch [in, out, k]         -> Conv1DTranspose kernel [k, out, in]
+  LSTM / LSTMCell   weight_ih [4u, in], weight_hh [4u, u], bias_ih + bias_hh   (gate order i, f, g, o = Keras i, f, c, o)
+                    -> kernel [in, 4u], recurrent_kernel [u, 4u], bias [4u]
+  BatchNorm1d       weight, bias, running_mean, running_var -> gamma, beta, moving_mean, moving_variance
+  weight_norm       weight_g, weight_v -> weight = g * v / ||v||   (norm over every dim but 0)
+  WaveGlow `cond_layer` (fused [8 * 1024, 640, 1]) is split per WN layer.
+
+No checkpoint ships with this repository (no network); `to_nvidia_*` builds NVIDIA-layout state dicts from the synthetic
+weights so that the mapping is exercised end to end by tests/test_weights_import.py.
+
+CLI:  python -m text_to_speech_amd.weights_import --tacotron2 tacotron2.pt --waveglow waveglow.pt -o model.ttsw
+"""
+from __future__ import annotations
+
+import argparse
+from collections import OrderedDict
+
+import numpy as np
+
+from .config import Tacotron2Config, WaveGlowConfig
+from .weights import save_ttsw, tacotron2_manifest, waveglow_manifest
+
+
+def _np(x):
+    if hasattr(x, 'detach'):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x, dtype=np.float32)
+
+
+def _strip(sd):
+    """Accepts a raw checkpoint ({'state_dict': ...}), DataParallel prefixes, and resolves weight_norm pairs."""
+    if 'state_dict' in sd and not any(k.endswith('.weight') for k in sd):
+        sd = sd['state_dict']
+    out = {}
+    for k, v in sd.items():
+        k = k[7:] if k.startswith('module.') else k
+        if k.endswith('num_batches_tracked'):
+            continue
+        out[k] = _np(v)
+    for k in [k for k in out if k.endswith('.weight_g')]:
+        base = k[:-len('.weight_g')]
+        g, v = out.pop(k), out.pop(base + '.weight_v')
+        norm = np.sqrt((v.astype(np.float64) ** 2).sum(axis=tuple(range(1, v.ndim)), keepdims=True))
+        out[base + '.weight'] = (g.astype(np.float64) * v / norm).astype(np.float32)
+    return out
+
+
+def _lstm(sd, prefix, suffix=''):
+    w_ih, w_hh = sd[f'{prefix}weight_ih{suffix}'], sd[f'{prefix}weight_hh{suffix}']
+    b = sd[f'{prefix}bias_ih{suffix}'] + sd[f'{prefix}bias_hh{suffix}']
+    return w_ih.T.copy(), w_hh.T.copy(), b
+
+
+def from_nvidia_tacotron2(state_dict, cfg: Tacotron2Config = Tacotron2Config()):
+    sd = _strip(state_dict)
+    o = OrderedDict()
+    p = 'tacotron2'
+    o[f'{p}/encoder/embeddings'] = sd['embedding.weight']
+    for i in range(cfg.encoder_n_conv):
+        o[f'{p}/encoder/conv_{i + 1}/kernel'] = sd[f'encoder.convolutions.{i}.0.conv.weight'].transpose(2, 1, 0).copy()
+        o[f'{p}/encoder/conv_{i + 1}/bias'] = sd[f'encoder.convolutions.{i}.0.conv.bias']
+        for src, dst in (('weight', 'gamma'), ('bias', 'beta'), ('running_mean', 'moving_mean'),
+                         ('running_var', 'moving_variance')):
+            o[f'{p}/encoder/norm_{i + 1}/{dst}'] = sd[f'encoder.convolutions.{i}.1.{src}']
+    for d, suf in (('forward', '_l0'), ('backward', '_l0_reverse')):
+        k, r, b = _lstm(sd, 'encoder.lstm.', suf)
+        o[f'{p}/encoder/bi_lstm/{d}/kernel'], o[f'{p}/encoder/bi_lstm/{d}/recurrent_kernel'] = k, r
+        o[f'{p}/encoder/bi_lstm/{d}/bias'] = b
+    for i in range(len(cfg.prenet_sizes)):
+        o[f'{p}/decoder/prenet/layer_{i}/kernel'] = sd[f'decoder.prenet.layers.{i}.linear_layer.weight'].T.copy()
+    for src, dst in (('decoder.attention_rnn.', 'attention_rnn'), ('decoder.decoder_rnn.', 'decoder_rnn/cell_0')):
+        k, r, b = _lstm(sd, src)
+        o[f'{p}/decoder/{dst}/kernel'], o[f'{p}/decoder/{dst}/recurrent_kernel'], o[f'{p}/decoder/{dst}/bias'] = k, r, b
+    a = 'decoder.attention_layer.'
+    o[f'{p}/decoder/lsa/query_layer/kernel'] = sd[a + 'query_layer.linear_layer.weight'].T.copy()
+    o[f'{p}/decoder/lsa/memory_layer/kernel'] = sd[a + 'memory_layer.linear_layer.weight'].T.copy()
+    o[f'{p}/decoder/lsa/value_layer/kernel'] = sd[a + 'v.linear_layer.weight'].T.copy()
+    o[f'{p}/decoder/lsa/location_conv/kernel'] = sd[a + 'location_layer.location_conv.conv.weight'].transpose(2, 1, 0).copy()
+    o[f'{p}/decoder/lsa/location_dense/kernel'] = sd[a + 'location_layer.location_dense.linear_layer.weight'].T.copy()
+    o[f'{p}/decoder/linear_projection/kernel'] = sd['decoder.linear_projection.linear_layer.weight'].T.copy()
+    o[f'{p}/decoder/linear_projection/bias'] = sd['decoder.linear_projection.linear_layer.bias']
+    o[f'{p}/decoder/gate_output/kernel'] = sd['decoder.gate_layer.linear_layer.weight'].T.copy()
+    o[f'{p}/decoder/gate_output/bias'] = sd['decoder.gate_layer.linear_layer.bias']
+    for i in range(cfg.postnet_n_conv):
+        o[f'{p}/postnet/conv_{i + 1}/kernel'] = sd[f'postnet.convolutions.{i}.0.conv.weight'].transpose(2, 1, 0).copy()
+        o[f'{p}/postnet/conv_{i + 1}/bias'] = sd[f'postnet.convolutions.{i}.0.conv.bias']
+        for src, dst in (('weight', 'gamma'), ('bias', 'beta'), ('running_mean', 'moving_mean'),
+                         ('running_var', 'moving_variance')):
+            o[f'{p}/postnet/norm_{i + 1}/{dst}'] = sd[f'postnet.convolutions.{i}.1.{src}']
+    return _checked(o, tacotron2_manifest(cfg))
+
+
+def from_nvidia_waveglow(state_dict, cfg: WaveGlowConfig = WaveGlowConfig()):
+    sd = _strip(state_dict)
+    o = OrderedDict()
+    o['waveglow/upsample/kernel'] = sd['upsample.weight'].transpose(2, 1, 0).copy()       # [in, out, k] -> [k, out, in]
+    o['waveglow/upsample/bias'] = sd['upsample.bias']
+    C2 = 2 * cfg.n_channels
+    for k in range(cfg.n_flows):
+        p, q = f'waveglow/block-{k}', f'WN.{k}.'
+        o[f'{p}/start_conv/kernel'] = sd[q + 'start.weight'].transpose(2, 1, 0).copy()
+        o[f'{p}/start_conv/bias'] = sd[q + 'start.bias']
+        fused = q + 'cond_layer.weight' in sd
+        for i in range(cfg.n_layers):
+            o[f'{p}/in_conv-{i}/kernel'] = sd[q + f'in_layers.{i}.weight'].transpose(2, 1, 0).copy()
+            o[f'{p}/in_conv-{i}/bias'] = sd[q + f'in_layers.{i}.bias']
+            if fused:
+                w = sd[q + 'cond_layer.weight'][i * C2:(i + 1) * C2]
+                b = sd[q + 'cond_layer.bias'][i * C2:(i + 1) * C2]
+            else:
+                w, b = sd[q + f'cond_layers.{i}.weight'], sd[q + f'cond_layers.{i}.bias']
+            o[f'{p}/cond_layer-{i}/kernel'] = w.transpose(2, 1, 0).copy()
+            o[f'{p}/cond_layer-{i}/bias'] = b.copy()
+            o[f'{p}/res_skip_conv-{i}/kernel'] = sd[q + f'res_skip_layers.{i}.weight'].transpose(2, 1, 0).copy()
+            o[f'{p}/res_skip_conv-{i}/bias'] = sd[q + f'res_skip_layers.{i}.bias']
+        o[f'{p}/end_conv/kernel'] = sd[q + 'end.weight'].transpose(2, 1, 0).copy()
+        o[f'{p}/end_conv/bias'] = sd[q + 'end.bias']
+        o[f'waveglow/invertible_conv-{k}/conv/kernel'] = sd[f'convinv.{k}.conv.weight'].transpose(2, 1, 0).copy()
+    return _checked(o, waveglow_manifest(cfg))
+
+
+def _checked(tensors, manifest):
+    out = OrderedDict()
+    for name, shape in manifest.items():
+        if name not in tensors:
+            raise KeyError(f'checkpoint has no tensor for {name}')
+        a = np.ascontiguousarray(tensors[name], dtype=np.float32)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f'{name}: converted shape {a.shape} != expected {shape}')
+        out[name] = a
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inverse mapping (tests / exporting synthetic weights to the NVIDIA layout)
+# ---------------------------------------------------------------------------------------------------------------------
+def to_nvidia_tacotron2(w, cfg: Tacotron2Config = Tacotron2Config(), rng=None):
+    """Keras-layout tensors -> NVIDIA state-dict layout.  bias_ih / bias_hh get a random split of the summed bias."""
+    rng = rng or np.random.default_rng(0)
+    p, sd = 'tacotron2', OrderedDict()
+    sd['embedding.weight'] = w[f'{p}/encoder/embeddings']
+
+    def bn(dst, src):
+        for a, b in (('weight', 'gamma'), ('bias', 'beta'), ('running_mean', 'moving_mean'), ('running_var', 'moving_variance')):
+            sd[f'{dst}.{a}'] = w[f'{src}/{b}']
+        sd[f'{dst}.num_batches_tracked'] = np.zeros((), np.float32)
+
+    def lstm(dst, src, suf=''):
+        b = w[f'{src}/bias']
+        b_ih = rng.standard_normal(b.shape).astype(np.float32)
+        sd[f'{dst}weight_ih{suf}'] = w[f'{src}/kernel'].T.copy()
+        sd[f'{dst}weight_hh{suf}'] = w[f'{src}/recurrent_kernel'].T.copy()
+        sd[f'{dst}bias_ih{suf}'], sd[f'{dst}bias_hh{suf}'] = b_ih, b - b_ih
+
+    for i in range(cfg.encoder_n_conv):
+        sd[f'encoder.convolutions.{i}.0.conv.weight'] = w[f'{p}/encoder/conv_{i + 1}/kernel'].transpose(2, 1, 0).copy()
+        sd[f'encoder.convolutions.{i}.0.conv.bias'] = w[f'{p}/encoder/conv_{i + 1}/bias']
+        bn(f'encoder.convolutions.{i}.1', f'{p}/encoder/norm_{i + 1}')
+    lstm('encoder.lstm.', f'{p}/encoder/bi_lstm/forward', '_l0')
+    lstm('encoder.lstm.', f'{p}/encoder/bi_lstm/backward', '_l0_reverse')
+    for i in range(len(cfg.prenet_sizes)):
+        sd[f'decoder.prenet.layers.{i}.linear_layer.weight'] = w[f'{p}/decoder/prenet/layer_{i}/kernel'].T.copy()
+    lstm('decoder.attention_rnn.', f'{p}/decoder/attention_rnn')
+    lstm('decoder.decoder_rnn.', f'{p}/decoder/decoder_rnn/cell_0')
+    a = 'decoder.attention_layer.'
+    sd[a + 'query_layer.linear_layer.weight'] = w[f'{p}/decoder/lsa/query_layer/kernel'].T.copy()
+    sd[a + 'memory_layer.linear_layer.weight'] = w[f'{p}/decoder/lsa/memory_layer/kernel'].T.copy()
+    sd[a + 'v.linear_layer.weight'] = w[f'{p}/decoder/lsa/value_layer/kernel'].T.copy()
+    sd[a + 'location_layer.location_conv.conv.weight'] = w[f'{p}/decoder/lsa/location_conv/kernel'].transpose(2, 1, 0).copy()
+    sd[a + 'location_layer.location_dense.linear_layer.weight'] = w[f'{p}/decoder/lsa/location_dense/kernel'].T.copy()
+    sd['decoder.linear_projection.linear_layer.weight'] = w[f'{p}/decoder/linear_projection/kernel'].T.copy()
+    sd['decoder.linear_projection.linear_layer.bias'] = w[f'{p}/decoder/linear_projection/bias']
+    sd['decoder.gate_layer.linear_layer.weight'] = w[f'{p}/decoder/gate_output/kernel'].T.copy()
+    sd['decoder.gate_layer.linear_layer.bias'] = w[f'{p}/decoder/gate_output/bias']
+    for i in range(cfg.postnet_n_conv):
+        sd[f'postnet.convolutions.{i}.0.conv.weight'] = w[f'{p}/postnet/conv_{i + 1}/kernel'].transpose(2, 1, 0).copy()
+        sd[f'postnet.convolutions.{i}.0.conv.bias'] = w[f'{p}/postnet/conv_{i + 1}/bias']
+        bn(f'postnet.convolutions.{i}.1', f'{p}/postnet/norm_{i + 1}')
+    return sd
+
+
+def to_nvidia_waveglow(w, cfg: WaveGlowConfig = WaveGlowConfig(), fused_cond=False, weight_norm=False, rng=None):
+    rng = rng or np.random.default_rng(0)
+    sd = OrderedDict()
+
+    def put(name, weight):
+        if weight_norm:                                         # g * v / ||v|| with a random rescaling of v
+            scale = rng.uniform(0.5, 2.0, (weight.shape[0],) + (1,) * (weight.ndim - 1)).astype(np.float32)
+            v = weight * scale
+            sd[name + '_v'] = v
+            sd[name + '_g'] = np.sqrt((weight.astype(np.float64) ** 2).sum(axis=tuple(range(1, weight.ndim)),
+                                                                            keepdims=True)).astype(np.float32)
+        else:
+            sd[name] = weight
+
+    put('upsample.weight', w['waveglow/upsample/kernel'].transpose(2, 1, 0).copy())
+    sd['upsample.bias'] = w['waveglow/upsample/bias']
+    for k in range(cfg.n_flows):
+        p, q = f'waveglow/block-{k}', f'WN.{k}.'
+        put(q + 'start.weight', w[f'{p}/start_conv/kernel'].transpose(2, 1, 0).copy())
+        sd[q + 'start.bias'] = w[f'{p}/start_conv/bias']
+        cw, cb = [], []
+        for i in range(cfg.n_layers):
+            put(q + f'in_layers.{i}.weight', w[f'{p}/in_conv-{i}/kernel'].transpose(2, 1, 0).copy())
+            sd[q + f'in_layers.{i}.bias'] = w[f'{p}/in_conv-{i}/bias']
+            cwi = w[f'{p}/cond_layer-{i}/kernel'].transpose(2, 1, 0).copy()
+            if fused_cond:
+                cw.append(cwi)
+                cb.append(w[f'{p}/cond_layer-{i}/bias'])
+            else:
+                put(q + f'cond_layers.{i}.weight', cwi)
+                sd[q + f'cond_layers.{i}.bias'] = w[f'{p}/cond_layer-{i}/bias']
+            put(q + f'res_skip_layers.{i}.weight', w[f'{p}/res_skip_conv-{i}/kernel'].transpose(2, 1, 0).copy())
+            sd[q + f'res_skip_layers.{i}.bias'] = w[f'{p}/res_skip_conv-{i}/bias']
+        if fused_cond:
+            put(q + 'cond_layer.weight', np.concatenate(cw, 0))
+            sd[q + 'cond_layer.bias'] = np.concatenate(cb, 0)
+        sd[q + 'end.weight'] = w[f'{p}/end_conv/kernel'].transpose(2, 1, 0).copy()
+        sd[q + 'end.bias'] = w[f'{p}/end_conv/bias']
+        sd[f'convinv.{k}.conv.weight'] = w[f'waveglow/invertible_conv-{k}/conv/kernel'].transpose(2, 1, 0).copy()
+    return sd
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    ap.add_argument('--tacotron2', help='NVIDIA Tacotron2 checkpoint (.pt)')
+    ap.add_argument('--waveglow', help='NVIDIA WaveGlow checkpoint (.pt, weight norm allowed)')
+    ap.add_argument('-o', '--output', required=True, help='TTSW file to write')
+    args = ap.parse_args(argv)
+    import torch
+    tensors = OrderedDict()
+    if args.tacotron2:
+        ck = torch.load(args.tacotron2, map_location='cpu')
+        tensors.update(from_nvidia_tacotron2(ck.get('state_dict', ck)))
+    if args.waveglow:
+        ck = torch.load(args.waveglow, map_location='cpu')
+        ck = ck.get('state_dict', ck) if isinstance(ck, dict) else ck
+        if hasattr(ck, 'state_dict'):
+            ck = ck.state_dict()
+        tensors.update(from_nvidia_waveglow(ck))
+    if not tensors:
+        ap.error('nothing to convert')
+    save_ttsw(args.output, tensors)
+    print(f'wrote {args.output}: {len(tensors)} tensors')
+
+
+if __name__ == '__main__':
+    main()
