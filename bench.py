@@ -100,6 +100,18 @@ def secondary_metrics(eng, dev, rank):
         eng.waveglow_infer(mel1, z=z1)
     dt = (time.perf_counter() - t0) / 3
     out['waveglow_batch1_samples_per_s'] = FRAMES * 256 / dt
+    # fp16-operand mode on the headline shape (BASELINE.json configs 3 / 5 run the vocoder in fp16); NOT the headline
+    # value, which stays exact fp32.  fp16 operands, fp32 accumulate: see DESIGN.md "fp16 mode".
+    mel8 = torch.from_numpy(np.random.default_rng(1).uniform(-11.5, 1.2, (BATCH, FRAMES, 80)).astype(np.float32)).to(dev)
+    z8 = torch.from_numpy(np.random.default_rng(2).standard_normal((BATCH, FRAMES * 32, 8)).astype(np.float32)).to(dev)
+    eng.waveglow_infer(mel8, z=z8, precision='f16')
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.waveglow_infer(mel8, z=z8, precision='f16')
+    dt = (time.perf_counter() - t0) / 3
+    out['waveglow_batch8_f16_samples_per_s'] = BATCH * FRAMES * 256 / dt
+    out['waveglow_batch8_f16_ms_per_step'] = dt * 1e3
+    del mel8, z8
     eng.load_state(weights.synth_tacotron2(Tacotron2Config(), seed=1234))
     eng.finalize()
     for B in (1, 8):

@@ -66,6 +66,12 @@ int tts_hip_has_model(const tts_hip_engine* e, const char* model);
  * audio [B, T*256] out                                                                                              */
 int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
                            float* audio, int mem);
+/* Same contract with fp16 GEMM operands (the reference's Keras mixed_float16 policy, utils/keras/gpu.py:32-34; BASELINE
+ * configs 3 and 5): activations, mel and weights are fp16 in HBM, accumulation and epilogue math are fp32, the residual
+ * stream and the flow state keep fp32 master copies; inputs / outputs stay float32.  The fp16 operands are derived from
+ * the finalized fp32 weights on first use.                                                                          */
+int tts_hip_waveglow_infer_f16(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                               float* audio, int mem);
 
 /* ---- Tacotron2.infer  (architectures/tacotron2_arch.py:866-925; called at models/tts/tacotron2.py:162)
  * tokens        int32 [B, Tin], 0 = pad

@@ -168,8 +168,8 @@ def test_runtime_argument_resolution_with_fake_engine():
             self.tokens = tokens
             return 'ok'
 
-        def waveglow_infer(self, mel, z=None, sigma=1.0):
-            self.z, self.sigma = z, sigma
+        def waveglow_infer(self, mel, z=None, sigma=1.0, precision='f32'):
+            self.z, self.sigma, self.precision = z, sigma, precision
             return np.zeros((mel.shape[0], mel.shape[1] * 256), np.float32)
 
     eng = Eng()
@@ -185,7 +185,15 @@ def test_runtime_argument_resolution_with_fake_engine():
     out = rt(np.zeros((2, 3, 80), np.float32), sigma=0.7)
     assert out.shape == (2, 768) and eng.z.shape == (2, 96, 8) and eng.sigma == 0.7
     rt(np.zeros((3, 80), np.float32), deterministic=True)
-    assert eng.z is None
+    assert eng.z is None and eng.precision == 'f32'
+    # vocoder precision: runtime-wide default, per-call override, validation
+    rt16 = HipRuntime('fake', engine=eng, vocoder_precision='f16')
+    rt16(np.zeros((1, 2, 80), np.float32), deterministic=True)
+    assert eng.precision == 'f16'
+    rt16(np.zeros((1, 2, 80), np.float32), deterministic=True, precision='f32')
+    assert eng.precision == 'f32'
+    with pytest.raises(ValueError, match='vocoder_precision'):
+        HipRuntime('fake', engine=eng, vocoder_precision='int8')
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -15,7 +15,7 @@ LIB_NAME = 'libtts_hip.so'
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipLibraryError(RuntimeError):
@@ -33,6 +33,7 @@ SIGNATURES = {
     'tts_hip_finalize': (c_int, [c_void_p]),
     'tts_hip_has_model': (c_int, [c_void_p, c_char_p]),
     'tts_hip_waveglow_infer': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int]),
+    'tts_hip_waveglow_infer_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int]),
     'tts_hip_tacotron2_infer': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     'tts_hip_mel_stft': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),

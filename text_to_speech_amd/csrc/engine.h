@@ -46,6 +46,9 @@ struct WgLayerDev {
     float* in_Bt = nullptr;     // [1024 (tanh/sigmoid interleaved per 128-tile)][3*512 taps] (first layer of a flow: [3*16])
     float* cond_Bt = nullptr;   // [32 phases][1024][320] conditioning conv folded with the upsampling kernel
     float* in_bias = nullptr;   // [1024] in_conv bias + cond bias (+ upsampling bias pushed through), same row order
+    _Float16* in_Bt16 = nullptr;    // fp16 operands of the optional fp16 path (built on first use): [1024][1536] (taps in
+    _Float16* cond_Bt16 = nullptr;  //   chunks of 32), [32][1024][4*96], [512][512]
+    _Float16* rs_Bt16 = nullptr;
     float* rs_Bt = nullptr;     // [512][512] residual half of res_skip (layers 0..6)
     float* rs_bias = nullptr;   // [512]
     int rs_n = 0;
@@ -64,6 +67,8 @@ struct WaveGlowDev {
     WgFlowDev flow[12];
     std::vector<void*> allocs;
     DevBuf x, acts, audio, a0p, io_mel, io_z, io_out;
+    bool f16_ready = false;
+    DevBuf x16, acts16, a0p16, mel16;        // fp16 path: shadow of x, activations, first-layer operand, mel
 };
 
 // ---------------------------------------------------------------- Tacotron2
@@ -147,7 +152,8 @@ void timing_collect(tts_hip_engine* e);
 
 // model entry points (device pointers only)
 int waveglow_finalize(tts_hip_engine* e);
-int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio);
+int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio,
+                 int precision);
 void waveglow_free(tts_hip_engine* e);
 
 int tacotron2_finalize(tts_hip_engine* e);

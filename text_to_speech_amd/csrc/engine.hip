@@ -71,7 +71,7 @@ void timing_collect(tts_hip_engine* e) {
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 1; }
+int tts_hip_abi_version(void) { return 2; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -195,8 +195,8 @@ int tts_hip_has_model(const tts_hip_engine* e, const char* model) {
     return 0;
 }
 
-int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
-                           float* audio, int mem) {
+static int waveglow_infer_impl(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                               float* audio, int mem, int precision) {
     if (!e) return TTS_HIP_EINVAL;
     if (!e->wg.ready) return set_err(e, TTS_HIP_ENOTREADY, "waveglow weights not finalized");
     if (!mel || !audio || B <= 0 || T <= 0) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: bad argument");
@@ -220,12 +220,22 @@ int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, co
     } else if (mem != TTS_HIP_MEM_DEVICE) {
         return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: bad mem kind %d", mem);
     }
-    int rc = waveglow_run(e, d_mel, B, T, d_z, sigma, d_out);
+    int rc = waveglow_run(e, d_mel, B, T, d_z, sigma, d_out, precision);
     if (rc) return rc;
     if (mem == TTS_HIP_MEM_HOST)
         HIPCHK(e, hipMemcpyAsync(audio, d_out, n_out * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return TTS_HIP_OK;
+}
+
+int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                           float* audio, int mem) {
+    return waveglow_infer_impl(e, mel, B, T, z, sigma, audio, mem, 0);
+}
+
+int tts_hip_waveglow_infer_f16(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                               float* audio, int mem) {
+    return waveglow_infer_impl(e, mel, B, T, z, sigma, audio, mem, 1);
 }
 
 int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem) {

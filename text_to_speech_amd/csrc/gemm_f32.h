@@ -22,6 +22,7 @@ namespace ttsgemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int MAX_SEG = 8;
 
@@ -65,6 +66,7 @@ struct GemmArgs {
     int act;
     int split;                      // columns [0, split) -> out0, [split, N) -> out1 (col - split); split == N: single output
     float* out0; long long ld0; int acc0;     // accN: add to the existing value (read-modify-write)
+    _Float16* out0h; long long ld0h;          // HALF kernels: fp16 output (gate) / fp16 shadow of out0 (linear); may be null
     float* out1; long long ld1; int acc1;
     long long strideOutZ;
     const uint8_t* rowmask;         // optional [M]: rows with mask 0 produce act(altbias[n]) instead
@@ -79,6 +81,17 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 __device__ __forceinline__ float sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// tanh(a) * sigmoid(b) = (E - 1) / ((E + 1) (1 + F)) with E = e^{2a}, F = e^{-b}: two v_exp_f32 and one v_rcp_f32 (1 ulp
+// each) instead of the libm tanhf / expf / IEEE division sequences, which made the gate epilogue ALU-bound (~0.3 ms of a
+// WN layer at config 2).  |a| is clamped at 15 (tanh(15) rounds to 1 in fp32) so E stays finite; b -> -inf gives
+// F = inf -> rcp(inf) = 0, the correct limit.  Absolute error < 1e-7 (tests/test_waveglow_gpu.py: parity unchanged).
+__device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
+    const float ac = fminf(fmaxf(a, -15.f), 15.f);
+    const float E = __builtin_amdgcn_exp2f(ac * 2.885390081777927f);      // 2 log2(e)
+    const float F = __builtin_amdgcn_exp2f(b * -1.4426950408889634f);
+    return (E - 1.f) * __builtin_amdgcn_rcpf((E + 1.f) * (1.f + F));
+}
 
 // Raw buffer loads: out-of-range offsets (>= num_records = 2^31) return 0, which gives branch-free zero fill for
 // rows outside the sequence / matrix (cdna_hip_programming.md T8).  Descriptors are built from wave-uniform values.
@@ -111,8 +124,13 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned by
 //           pipe); the LDS image is unpadded 64-B rows, XOR-swizzled through the per-lane SOURCE address (a wave
 //           instruction writes 1 KiB linearly, cdna_hip_programming.md rule 21), triple buffered.
 enum { PIPE_REG = 0, PIPE_DMA = 1 };
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG>
-__global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
+// HALF: the operands are fp16 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Everything outside the MFMA call and the
+// epilogue stores works on 4-byte units, so an fp16 operand is described to the kernel in "float units": ld, k, kpad, ldb
+// are HALF the element counts and one 16-byte LDS fragment (4 float units) carries 8 halfs = the K = 16 slice of one
+// MFMA -- the DMA pipeline, the swizzle and the segment addressing are shared with the fp32 kernel.
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false>
+__global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmArgs g) {
+    static_assert(!HALF || PIPE == PIPE_DMA, "fp16 operands use the LDS-DMA pipeline");
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
     constexpr bool DMA = PIPE == PIPE_DMA;
@@ -120,10 +138,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int LDSK = DMA ? BK : BK + 4; // LDS row in floats: padded (144 B / 80 B) or swizzled 64 B
     constexpr int NBUF = DMA ? 3 : 2;
     constexpr int TPR = BK / 4;             // threads (float4) per tile row
-    constexpr int RPP = 256 / TPR;          // rows staged per pass of the 256 threads
+    constexpr int NT = WR * WC * 64;        // threads: 4 waves (one per SIMD) or 8 (two per SIMD, one block per CU)
+    constexpr int RPP = NT / TPR;           // rows staged per pass of the block's threads
     constexpr int PA = BM / RPP;            // float4 loads per thread for the A tile
     constexpr int PB = BN / RPP;
-    static_assert(WR * WC == 4, "4 waves");
+    static_assert(WR * WC == 4 || WR * WC == 8, "4 or 8 waves");
     static_assert(BK == 16 || BK == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -352,13 +371,23 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
         for (int i = 0; i < RT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
 #pragma unroll
         for (int j = 0; j < CT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        if constexpr (HALF) {
+            // lane (row, h) holds k = 8h .. 8h+7 of this 16-wide K slice: exactly the 32x32x16 f16 operand layout
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]),
+                                                                       __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+        }
     };
 
     if (nSeq > 0) enter_segment();
@@ -381,13 +410,21 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0, bufn = 2;                       // buffer of tile t, buffer for tile t+2
+#ifndef TTS_ABL
+#define TTS_ABL 0
+#endif
+        constexpr int ABL = HALF ? TTS_ABL : 0;      // timing ablations of the fp16 loop (results are garbage when != 0)
         for (int t = 0; t < nAll; ++t) {
-            dma_tile(bufn);
+            if (ABL != 2) dma_tile(bufn);
+            if (ABL != 3) {
 #pragma unroll
-            for (int k8 = 0; k8 < BK / 8; ++k8) compute_chunk(buf, k8);
-            if (t + 2 < nAll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+                for (int k8 = 0; k8 < BK / 8; ++k8) compute_chunk(buf, k8);
+            }
+            if (ABL != 1) {
+                if (t + 2 < nAll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             buf = buf == 2 ? 0 : buf + 1;
             bufn = bufn == 2 ? 0 : bufn + 1;
         }
@@ -431,24 +468,24 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
 
     // ---------------- epilogue ----------------
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if constexpr (WC == 1 && CT % 2 == 0) {
+    if constexpr (CT % 2 == 0) {
         if (g.mode == EPI_GATE) {
-            // columns [n0, n0 + BN/2) hold the tanh pre-activations, [n0 + BN/2, n0 + BN) the matching sigmoid
-            // pre-activations (weight rows are permuted at load time); output channel = nt * BN/2 + local column.
+            // a wave's CT*32 columns hold CT*16 tanh pre-activations followed by the matching sigmoid pre-activations
+            // (weight rows are permuted at load time in groups of CT*32); output channel = group * CT*16 + local column.
             constexpr int H = CT / 2;
             float* out = outp;
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < H; ++j) {
-                    const int ch = nt * (BN / 2) + j * 32 + li;
+                    const int ch = (nt * WC + wc) * (CT * 16) + j * 32 + li;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
                         if (m < g.M) {
-                            const float tv = tanhf(acc[i][j][r]);
-                            const float sv = sigmoid_exact(acc[i][j + H][r]);
-                            out[(long long)m * g.ld0 + ch] = tv * sv;
+                            const float gv = gate_tanh_sigmoid(acc[i][j][r], acc[i][j + H][r]);
+                            if constexpr (HALF) g.out0h[(long long)m * g.ld0h + ch] = (_Float16)gv;
+                            else out[(long long)m * g.ld0 + ch] = gv;
                         }
                     }
                 }
@@ -472,13 +509,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_f32_kernel(const GemmArgs g) {
                         const bool on = g.rowmask[m] != 0;
                         v = on ? v : (g.mask_out ? 0.f : ab);
                     }
-                    outp[(long long)m * ldo + nc] = act_apply(v, g.act);
+                    const float ov = act_apply(v, g.act);
+                    outp[(long long)m * ldo + nc] = ov;
+                    if constexpr (HALF) {
+                        if (g.out0h && !second) g.out0h[(long long)m * g.ld0h + nc] = (_Float16)ov;
+                    }
                 }
             }
         }
 }
 
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG>
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
@@ -501,7 +542,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
                 g.seg[i].ld != g.seg[0].ld)
                 return hipErrorInvalidValue;
     }
-    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE>;
+    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE, HALF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -509,7 +550,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
         attr_set = true;
     }
     dim3 grid(numMt8 * numNt, 1, batch_z);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
+    hipLaunchKernelGGL(kern, grid, dim3(WR * WC * 64), lds, stream, g);
     return hipGetLastError();
 }
 
@@ -533,6 +574,28 @@ inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_g
 // 128-row-tile variants: used when padding the phase blocks to 256 rows would waste more work (e.g. batch 1)
 inline hipError_t gemm_wn_in_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 inline hipError_t gemm_wn_in0_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+// fp16-operand variants (activations and weights fp16 in HBM, fp32 accumulate): same tiles and pipeline
+#ifndef TTS_H_WC
+#define TTS_H_WC 2     // fp16 in-layer GEMM: 8 waves, 256 x 256 block tile (the fp16 loop is bound by L2 -> LDS traffic)
+#endif
+inline hipError_t gemm_wn_in_h(const GemmArgs& g, bool t128, hipStream_t s) {
+    if (!t128 && TTS_H_WC == 2)
+        return launch_gemm<TTS_WN_WR, 2, TTS_WN_RT, 4, TTS_WN_BK, 1, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s);
+    return t128 ? launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s)
+                : launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s);
+}
+inline hipError_t gemm_wn_in0_h(const GemmArgs& g, bool t128, hipStream_t s) {
+    return t128 ? launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true>(g, 1, s)
+                : launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true>(g, 1, s);
+}
+#ifndef TTS_HRES_WC
+#define TTS_HRES_WC 1
+#define TTS_HRES_RT 1
+#define TTS_HRES_OCC 3
+#endif
+inline hipError_t gemm_wn_res_h(const GemmArgs& g, hipStream_t s) {
+    return launch_gemm<TTS_WN_WR, TTS_HRES_WC, TTS_HRES_RT, 4, TTS_WN_BK, TTS_HRES_OCC, TAG_WN_RES_SKIP, 0, PIPE_DMA, true>(g, 1, s);
+}
 // first layer of a flow (start conv composed into the taps: K = 48 + 320); own TAG so profiles list it separately
 inline hipError_t gemm_wn_in0(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 #ifndef TTS_WN_RES_RT

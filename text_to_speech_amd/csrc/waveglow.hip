@@ -101,6 +101,37 @@ __global__ void cond_bias_kernel(const float* __restrict__ wct, const float* __r
     bias[n] += acc;
 }
 
+// ---- fp16 operand builders (run once, on first use of the fp16 path, from the packed fp32 device copies)
+__global__ void cvt_half_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (_Float16)src[i];
+}
+// in-layer taps: fp32 [1024][1536] tap-interleaved in chunks of 16 -> fp16 [1024][1536] tap-interleaved in chunks of 32
+// (the fp16 kernel's K step is 32 halfs = 64-byte LDS rows, like 16 floats)
+__global__ void cvt_taps_kernel(const float* __restrict__ src, _Float16* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)2 * C * KCONV) return;
+    const int n = (int)(i / KCONV), r = (int)(i % KCONV);
+    const int tap = r / C, c = r % C;
+    const int ks = (c / 16) * 48 + tap * 16 + c % 16, kd = (c / 32) * 96 + tap * 32 + c % 32;
+    dst[(long long)n * KCONV + kd] = (_Float16)src[(long long)n * KCONV + ks];
+}
+// first layer of a flow: fp32 [1024][3*16] -> fp16 [1024][3*32] (a0p rows are 32 halfs)
+__global__ void cvt_taps0_kernel(const float* __restrict__ src, _Float16* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * C * 96) return;
+    const int n = i / 96, r = i % 96, tap = r / 32, jj = r % 32;
+    dst[i] = jj < 16 ? (_Float16)src[n * KCONV0 + tap * 16 + jj] : (_Float16)0.f;
+}
+// folded conditioning: fp32 [32][1024][4*80] -> fp16 [32][1024][4*96] (each mel frame padded to 96 = 3 K steps)
+__global__ void cvt_cond_kernel(const float* __restrict__ src, _Float16* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)NPH * 2 * C * 384) return;
+    const long long row = i / 384;
+    const int r = (int)(i % 384), q = r / 96, jj = r % 96;
+    dst[i] = jj < 80 ? (_Float16)src[row * KMEL + q * 80 + jj] : (_Float16)0.f;
+}
+
 // audio[m'][0..3] = sigma * z[natural m][0..3]  (z null => zeros); m' = p * PR + f  <->  m = f * 32 + p
 __global__ void init_audio_kernel(const float* __restrict__ z, float sigma, float* __restrict__ audio, int PR, int BT) {
     const long long mp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,23 +148,33 @@ __global__ void init_audio_kernel(const float* __restrict__ z, float sigma, floa
 }
 
 // x[m][c] = sum_{j < h} audio[m][j] * w[j][c] + b[c]      (start 1x1 conv, waveglow_arch.py:108)
-// Also writes a0p[m][0..15] = [audio_0 (h values) | 1 | 0 ...]: the operand of the first WN layer, whose dilated conv is
+// Also writes a0p[m][..] = [audio_0 (h values) | 1 | 0 ...]: the operand of the first WN layer, whose dilated conv is
 // composed with the start conv at load time (the constant 1 carries the start bias through the zero padding).
+// HALF: x stays fp32 (master copy for the residual accumulation) and additionally gets an fp16 shadow x16 (the GEMM
+// operand); a0p is written as 32 halfs per row.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <bool HALF>
 __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __restrict__ w,
-                                const float* __restrict__ b, float* __restrict__ x, float* __restrict__ a0p,
-                                long long M, int h) {
+                                const float* __restrict__ b, float* __restrict__ x, void* __restrict__ a0p_v,
+                                _Float16* __restrict__ x16, long long M, int h) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of channels
     if (idx >= M * (C / 4)) return;
     const long long m = idx / (C / 4);
     const int c = (int)(idx % (C / 4)) * 4;
-    if (c < 16) {                                       // 4 threads of the row write the 16-float a0p row
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < (HALF ? 32 : 16)) {                         // the first threads of the row also write the a0p row
+        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = c + j;
             v[j] = col < h ? audio[m * 8 + col] : (col == h ? 1.f : 0.f);
         }
-        *reinterpret_cast<f32x4*>(a0p + m * 16 + c) = v;
+        if constexpr (HALF) {
+            const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<f16x4*>((_Float16*)a0p_v + m * 32 + c) = hv;
+        } else {
+            const f32x4 fv = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>((float*)a0p_v + m * 16 + c) = fv;
+        }
     }
     f32x4 acc = *reinterpret_cast<const f32x4*>(b + c);
     // the reference accumulates the dot product first and adds the bias last (Conv1D = conv + bias)
@@ -145,6 +186,10 @@ __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __
     }
     acc += s;
     *reinterpret_cast<f32x4*>(x + m * C + c) = acc;
+    if constexpr (HALF) {
+        const f16x4 hv = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+        *reinterpret_cast<f16x4*>(x16 + m * C + c) = hv;
+    }
 }
 
 // Folded skip/end conv + affine inverse + inverse 1x1 conv (+ early-z prepend), RPW positions per wave.
@@ -153,7 +198,8 @@ __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __
 // Lane l owns channels 8l..8l+7; per layer the lane's 8x8 slice of wfold sits in registers and is reused for the RPW
 // rows; the RPW*8 partial sums are reduced with the lane-halving exchange (63 shuffles for 64 values).
 constexpr int RPW = 8;
-__global__ __launch_bounds__(256) void wn_end_fold_kernel(const float* __restrict__ acts, long long layer_stride,
+template <bool HALF>
+__global__ __launch_bounds__(256) void wn_end_fold_kernel(const void* __restrict__ acts_v, long long layer_stride,
                                                           const float* __restrict__ wfold,
                                                           const float* __restrict__ bfold,
                                                           const float* __restrict__ inv, float* __restrict__ audio_io,
@@ -176,12 +222,18 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const float* __restric
             w0[o] = *reinterpret_cast<const f32x4*>(wl + o * C);
             w1[o] = *reinterpret_cast<const f32x4*>(wl + o * C + 4);
         }
-        const float* al = acts + layer * layer_stride + lane * 8;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const long long m = m0 + r < M ? m0 + r : M - 1;       // clamp: tail rows are computed but never stored
-            a0[r] = *reinterpret_cast<const f32x4*>(al + m * C);
-            a1[r] = *reinterpret_cast<const f32x4*>(al + m * C + 4);
+            if constexpr (HALF) {
+                const f16x8 hv = *reinterpret_cast<const f16x8*>((const _Float16*)acts_v + layer * layer_stride + m * C + lane * 8);
+                a0[r] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                a1[r] = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+            } else {
+                const float* al = (const float*)acts_v + layer * layer_stride + lane * 8;
+                a0[r] = *reinterpret_cast<const f32x4*>(al + m * C);
+                a1[r] = *reinterpret_cast<const f32x4*>(al + m * C + 4);
+            }
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -257,6 +309,11 @@ void waveglow_free(tts_hip_engine* e) {
     e->wg.acts.release();
     e->wg.audio.release();
     e->wg.a0p.release();
+    e->wg.x16.release();
+    e->wg.acts16.release();
+    e->wg.a0p16.release();
+    e->wg.mel16.release();
+    e->wg.f16_ready = false;
     e->wg.io_mel.release();
     e->wg.io_z.release();
     e->wg.io_out.release();
@@ -480,8 +537,60 @@ int waveglow_finalize(tts_hip_engine* e) {
     return TTS_HIP_OK;
 }
 
-int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio) {
+// Builds the fp16 GEMM operands from the packed fp32 device copies (once).
+static int waveglow_build_f16(tts_hip_engine* e) {
     WaveGlowDev& wg = e->wg;
+    if (wg.f16_ready) return TTS_HIP_OK;
+    hipStream_t st = e->stream;
+    auto alloc_h = [&](size_t n, _Float16** out) -> int {
+        void* p = nullptr;
+        HIPCHK(e, hipMalloc(&p, n * sizeof(_Float16)));
+        wg.allocs.push_back(p);
+        *out = (_Float16*)p;
+        return TTS_HIP_OK;
+    };
+    int rc;
+    for (int k = 0; k < 12; ++k)
+        for (int i = 0; i < 8; ++i) {
+            WgLayerDev& ly = wg.flow[k].layer[i];
+            _Float16 *a, *c, *r = nullptr;
+            if (i == 0) {
+                if ((rc = alloc_h((size_t)2 * C * 96, &a))) return rc;
+                hipLaunchKernelGGL(cvt_taps0_kernel, dim3((2 * C * 96 + 255) / 256), dim3(256), 0, st, ly.in_Bt, a);
+            } else {
+                if ((rc = alloc_h((size_t)2 * C * KCONV, &a))) return rc;
+                const long long n = (long long)2 * C * KCONV;
+                hipLaunchKernelGGL(cvt_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.in_Bt, a);
+            }
+            if ((rc = alloc_h((size_t)NPH * 2 * C * 384, &c))) return rc;
+            {
+                const long long n = (long long)NPH * 2 * C * 384;
+                hipLaunchKernelGGL(cvt_cond_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.cond_Bt, c);
+            }
+            if (ly.rs_n) {
+                if ((rc = alloc_h((size_t)C * C, &r))) return rc;
+                hipLaunchKernelGGL(cvt_half_kernel, dim3((C * C + 255) / 256), dim3(256), 0, st, ly.rs_Bt, r, (long long)C * C);
+            }
+            HIPCHK(e, hipGetLastError());
+            ly.in_Bt16 = a;
+            ly.cond_Bt16 = c;
+            ly.rs_Bt16 = r;
+        }
+    HIPCHK(e, hipStreamSynchronize(st));
+    wg.f16_ready = true;
+    return TTS_HIP_OK;
+}
+
+// precision 0: exact fp32 MFMA path.  precision 1: fp16 operands (activations, mel and weights fp16 in HBM), fp32
+// accumulation and fp32 epilogue math, fp32 master copy of the residual stream and of the flow state.
+int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio,
+                 int precision) {
+    WaveGlowDev& wg = e->wg;
+    const bool half = precision == 1;
+    if (half) {
+        int rc = waveglow_build_f16(e);
+        if (rc) return rc;
+    }
     const int BT = B * T;                                        // frames
     // rows per phase block, padded to the M tile: 256-row tiles unless 128-row tiles save at least 5 % of the rows
     const int pr256 = (BT + 255) / 256 * 256, pr128 = (BT + 127) / 128 * 128;
@@ -491,13 +600,27 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     if ((double)M * C * 4.0 >= 2147483648.0 - 65536.0)
         return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: B*T = %d frames exceeds one call's limit (~32000)", BT);
     HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
-    HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));          // activations of the 8 layers of one flow
     HIPCHK(e, wg.audio.ensure((size_t)M * 8 * 4));
-    HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
+    if (half) {
+        HIPCHK(e, wg.x16.ensure((size_t)M * C * 2));
+        HIPCHK(e, wg.acts16.ensure((size_t)8 * M * C * 2));
+        HIPCHK(e, wg.a0p16.ensure((size_t)M * 32 * 2));
+        HIPCHK(e, wg.mel16.ensure((size_t)BT * 80 * 2 + 256));
+    } else {
+        HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));      // activations of the 8 layers of one flow
+        HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
+    }
     hipStream_t st = e->stream;
+    _Float16* x16 = (_Float16*)wg.x16.p;
+    _Float16* acts16 = (_Float16*)wg.acts16.p;
+    _Float16* mel16 = (_Float16*)wg.mel16.p;
 
     const unsigned mb = (unsigned)((M + 255) / 256);
     hipLaunchKernelGGL(init_audio_kernel, dim3(mb), dim3(256), 0, st, d_z, sigma, wg.audio.f(), PR, BT);
+    if (half) {
+        const long long n = (long long)BT * 80;
+        hipLaunchKernelGGL(cvt_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mel, mel16, n);
+    }
     HIPCHK(e, hipGetLastError());
 
     int zoff = 4;
@@ -506,8 +629,13 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         const int h = fl.n_half;
         {
             const long long n4 = M * (C / 4);
-            hipLaunchKernelGGL(wn_start_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, wg.audio.f(),
-                               fl.start_w, fl.start_b, wg.x.f(), wg.a0p.f(), M, h);
+            const dim3 grid((unsigned)((n4 + 255) / 256));
+            if (half)
+                hipLaunchKernelGGL(wn_start_kernel<true>, grid, dim3(256), 0, st, wg.audio.f(), fl.start_w, fl.start_b,
+                                   wg.x.f(), wg.a0p16.p, x16, M, h);
+            else
+                hipLaunchKernelGGL(wn_start_kernel<false>, grid, dim3(256), 0, st, wg.audio.f(), fl.start_w, fl.start_b,
+                                   wg.x.f(), wg.a0p.p, (_Float16*)nullptr, M, h);
             HIPCHK(e, hipGetLastError());
         }
         for (int i = 0; i < 8; ++i) {
@@ -520,58 +648,111 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.phase_rows = PR;
             g.frames = BT;
             g.nseg = 7;
-            if (i == 0) {
-                // first layer: conv(start(a0)) composed at load time -> K = 3 taps x 16 (h + 1 used) instead of 3 x 512
-                for (int tap = 0; tap < 3; ++tap) g.seg[tap] = ASeg{wg.a0p.f(), 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP};
-                g.ldb = KCONV0;
-            } else {
-                for (int tap = 0; tap < 3; ++tap) g.seg[tap] = ASeg{wg.x.f(), C, (tap - 1) * d, C, C, SEG_PHASE_TAP};
-                g.ldb = KCONV;
-            }
-            // folded conditioning: mel frames t, t-1, t-2, t-3 against the per-phase weights V_{i,p}
-            for (int q = 0; q < 4; ++q) g.seg[3 + q] = ASeg{d_mel, 80, -q, 80, 80, SEG_FRAME};
-            g.Bt = ly.in_Bt;
-            g.Bt2 = ly.cond_Bt;
-            g.ldb2 = KMEL;
-            g.strideB2p = (long long)2 * C * KMEL;
             g.bias = ly.in_bias;
             g.mode = EPI_GATE;
-            float* acts_i = wg.acts.f() + (size_t)i * M * C;
-            g.out0 = acts_i;
-            g.ld0 = C;
             g.split = 2 * C;
-            timing_begin(e, i == 0 ? 3 : 0);
-            if (i == 0) HIPCHK(e, tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
-            else HIPCHK(e, tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
-            timing_end(e);
-
-            if (i < 7) {                 // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
-                GemmArgs r{};
-                r.M = (int)M;
-                r.N = C;
-                r.L = (int)M;
-                r.nseg = 1;
-                r.seg[0] = ASeg{acts_i, C, 0, C, C};
-                r.Bt = ly.rs_Bt;
-                r.ldb = C;
-                r.bias = ly.rs_bias;
-                r.mode = EPI_LINEAR;
-                r.act = ACT_NONE;
-                r.split = C;
-                r.out0 = wg.x.f();
-                r.ld0 = C;
-                r.acc0 = 1;
-                timing_begin(e, 1);
-                HIPCHK(e, gemm_wn_res_skip(r, st));
+            if (!half) {
+                if (i == 0) {
+                    // first layer: conv(start(a0)) composed at load time -> K = 3 taps x 16 (h + 1 used) instead of 3 x 512
+                    for (int tap = 0; tap < 3; ++tap) g.seg[tap] = ASeg{wg.a0p.f(), 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP};
+                    g.ldb = KCONV0;
+                } else {
+                    for (int tap = 0; tap < 3; ++tap) g.seg[tap] = ASeg{wg.x.f(), C, (tap - 1) * d, C, C, SEG_PHASE_TAP};
+                    g.ldb = KCONV;
+                }
+                // folded conditioning: mel frames t, t-1, t-2, t-3 against the per-phase weights V_{i,p}
+                for (int q = 0; q < 4; ++q) g.seg[3 + q] = ASeg{d_mel, 80, -q, 80, 80, SEG_FRAME};
+                g.Bt = ly.in_Bt;
+                g.Bt2 = ly.cond_Bt;
+                g.ldb2 = KMEL;
+                g.strideB2p = (long long)2 * C * KMEL;
+                float* acts_i = wg.acts.f() + (size_t)i * M * C;
+                g.out0 = acts_i;
+                g.ld0 = C;
+                timing_begin(e, i == 0 ? 3 : 0);
+                if (i == 0) HIPCHK(e, tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
+                else HIPCHK(e, tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
                 timing_end(e);
+                if (i < 7) {             // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
+                    GemmArgs r{};
+                    r.M = (int)M;
+                    r.N = C;
+                    r.L = (int)M;
+                    r.nseg = 1;
+                    r.seg[0] = ASeg{acts_i, C, 0, C, C};
+                    r.Bt = ly.rs_Bt;
+                    r.ldb = C;
+                    r.bias = ly.rs_bias;
+                    r.mode = EPI_LINEAR;
+                    r.act = ACT_NONE;
+                    r.split = C;
+                    r.out0 = wg.x.f();
+                    r.ld0 = C;
+                    r.acc0 = 1;
+                    timing_begin(e, 1);
+                    HIPCHK(e, gemm_wn_res_skip(r, st));
+                    timing_end(e);
+                }
+            } else {
+                // fp16 operands, described in float units (one unit = 2 halfs): ld / k / kpad / ldb are halved
+                if (i == 0) {
+                    for (int tap = 0; tap < 3; ++tap)
+                        g.seg[tap] = ASeg{(const float*)wg.a0p16.p, 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP};
+                    g.ldb = 96 / 2;
+                } else {
+                    for (int tap = 0; tap < 3; ++tap)
+                        g.seg[tap] = ASeg{(const float*)x16, C / 2, (tap - 1) * d, C / 2, C / 2, SEG_PHASE_TAP};
+                    g.ldb = KCONV / 2;
+                }
+                for (int q = 0; q < 4; ++q) g.seg[3 + q] = ASeg{(const float*)mel16, 40, -q, 40, 48, SEG_FRAME};
+                g.Bt = (const float*)ly.in_Bt16;
+                g.Bt2 = (const float*)ly.cond_Bt16;
+                g.ldb2 = 384 / 2;
+                g.strideB2p = (long long)2 * C * 384 / 2;
+                _Float16* acts_i = acts16 + (size_t)i * M * C;
+                g.out0 = wg.x.f();           // unused by the gate epilogue (fp16 output below)
+                g.ld0 = C;
+                g.out0h = acts_i;
+                g.ld0h = C;
+                timing_begin(e, i == 0 ? 3 : 0);
+                HIPCHK(e, i == 0 ? gemm_wn_in0_h(g, tile128, st) : gemm_wn_in_h(g, tile128, st));
+                timing_end(e);
+                if (i < 7) {
+                    GemmArgs r{};
+                    r.M = (int)M;
+                    r.N = C;
+                    r.L = (int)M;
+                    r.nseg = 1;
+                    r.seg[0] = ASeg{(const float*)acts_i, C / 2, 0, C / 2, C / 2};
+                    r.Bt = (const float*)ly.rs_Bt16;
+                    r.ldb = C / 2;
+                    r.bias = ly.rs_bias;
+                    r.mode = EPI_LINEAR;
+                    r.act = ACT_NONE;
+                    r.split = C;
+                    r.out0 = wg.x.f();       // fp32 master of the residual stream (read-modify-write)
+                    r.ld0 = C;
+                    r.acc0 = 1;
+                    r.out0h = x16;           // fp16 shadow = operand of the next layer's taps
+                    r.ld0h = C;
+                    timing_begin(e, 1);
+                    HIPCHK(e, gemm_wn_res_h(r, st));
+                    timing_end(e);
+                }
             }
         }
         const bool early = (k % 4 == 0) && k > 0;
         float* dst = (k == 0) ? d_audio : wg.audio.f();
         const long long waves = (M + RPW - 1) / RPW;
-        hipLaunchKernelGGL(wn_end_fold_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, wg.acts.f(),
-                           (long long)M * C, fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, k == 0 ? 1 : 0, d_z, zoff,
-                           early ? 2 : 0, sigma, M, h, PR, BT);
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        if (half)
+            hipLaunchKernelGGL(wn_end_fold_kernel<true>, grid, dim3(256), 0, st, (const void*)acts16, (long long)M * C,
+                               fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, k == 0 ? 1 : 0, d_z, zoff, early ? 2 : 0,
+                               sigma, M, h, PR, BT);
+        else
+            hipLaunchKernelGGL(wn_end_fold_kernel<false>, grid, dim3(256), 0, st, (const void*)wg.acts.p,
+                               (long long)M * C, fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, k == 0 ? 1 : 0, d_z,
+                               zoff, early ? 2 : 0, sigma, M, h, PR, BT);
         HIPCHK(e, hipGetLastError());
         if (early) zoff += 2;
     }

@@ -80,8 +80,11 @@ class HipEngine:
         return bool(self._lib.tts_hip_has_model(self._h, model.encode()))
 
     # ------------------------------------------------------------------ WaveGlow
-    def waveglow_infer(self, mel, z=None, sigma: float = 1.0):
-        """mel [B, T, 80] (+ optional z [B, T*32, 8]) -> audio [B, T*256]."""
+    def waveglow_infer(self, mel, z=None, sigma: float = 1.0, precision: str = 'f32'):
+        """mel [B, T, 80] (+ optional z [B, T*32, 8]) -> audio [B, T*256].  precision: 'f32' (exact) or 'f16' operands."""
+        if precision not in ('f32', 'f16'):
+            raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
+        fn = self._lib.tts_hip_waveglow_infer if precision == 'f32' else self._lib.tts_hip_waveglow_infer_f16
         if _is_torch_cuda(mel):
             torch = self._torch()
             mel = mel.to(torch.float32).contiguous()
@@ -96,9 +99,8 @@ class HipEngine:
                 zp = ctypes.c_void_p(z.data_ptr())
             out = torch.empty((B, T * 256), dtype=torch.float32, device=mel.device)
             self._sync_torch()
-            self._check(self._lib.tts_hip_waveglow_infer(self._h, ctypes.c_void_p(mel.data_ptr()), B, T, zp,
-                                                         float(sigma), ctypes.c_void_p(out.data_ptr()), MEM_DEVICE),
-                        'waveglow_infer')
+            self._check(fn(self._h, ctypes.c_void_p(mel.data_ptr()), B, T, zp, float(sigma),
+                           ctypes.c_void_p(out.data_ptr()), MEM_DEVICE), 'waveglow_infer')
             return out
         mel = np.ascontiguousarray(mel, dtype=np.float32)
         if mel.ndim != 3 or mel.shape[2] != 80:
@@ -111,9 +113,8 @@ class HipEngine:
                 raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {z.shape}')
             zp = z.ctypes.data_as(ctypes.c_void_p)
         out = np.empty((B, T * 256), dtype=np.float32)
-        self._check(self._lib.tts_hip_waveglow_infer(self._h, mel.ctypes.data_as(ctypes.c_void_p), B, T, zp,
-                                                     float(sigma), out.ctypes.data_as(ctypes.c_void_p), MEM_HOST),
-                    'waveglow_infer')
+        self._check(fn(self._h, mel.ctypes.data_as(ctypes.c_void_p), B, T, zp, float(sigma),
+                       out.ctypes.data_as(ctypes.c_void_p), MEM_HOST), 'waveglow_infer')
         return out
 
     # ------------------------------------------------------------------ Tacotron2

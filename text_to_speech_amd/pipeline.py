@@ -14,8 +14,9 @@ PAD_MEL_VALUE = -11.0
 
 
 class TTSPipeline:
-    def __init__(self, engine, seed=None):
+    def __init__(self, engine, seed=None, vocoder_precision='f32'):
         self.engine = engine
+        self.vocoder_precision = vocoder_precision      # 'f16': BASELINE.json configs 3 / 5
         self._rng = np.random.default_rng(seed)
 
     def synthesize_tokens(self, tokens, speaker=None, max_length=10.0, deterministic=False, prenet_masks=None, z=None,
@@ -51,7 +52,7 @@ class TTSPipeline:
             z = torch.from_numpy(self._rng.standard_normal((B, T * 32, 8)).astype(np.float32)).to(dev)
         elif z is not None:
             z = torch.as_tensor(z, dtype=torch.float32).to(dev)[:, :T * 32]
-        audio = eng.waveglow_infer(mel.contiguous(), z=z, sigma=sigma)
+        audio = eng.waveglow_infer(mel.contiguous(), z=z, sigma=sigma, precision=self.vocoder_precision)
         audio_h = audio.cpu().numpy()
         n = lengths.cpu().numpy()
         return [audio_h[b, :int(n[b]) * 256].copy() for b in range(B)], n, steps

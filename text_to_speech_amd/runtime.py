@@ -56,6 +56,8 @@ class HipRuntime(Runtime):
     path   : a TTSW weight file (text_to_speech_amd.weights.save_ttsw), or 'synthetic' / 'synthetic:<seed>' for the
              seeded synthetic weights of SURVEY.md section 8d.
     model  : 'tacotron2' | 'waveglow' | None (None: dispatch on the input dtype -- integer tokens vs float mels).
+    vocoder_precision : 'f32' (exact fp32 MFMA, default) or 'f16' (fp16 GEMM operands with fp32 accumulation: the
+             counterpart of the reference's `mixed_float16` policy, utils/keras/gpu.py).
     """
 
     def __init__(self, path, *, model=None, engine=None, reload=False, device=0, seed=None, **kwargs):
@@ -63,6 +65,9 @@ class HipRuntime(Runtime):
         self.model = model
         self._rng = np.random.default_rng(seed)
         self.max_decoder_steps = int(kwargs.get('max_decoder_steps', 2000))
+        self.vocoder_precision = kwargs.get('vocoder_precision', 'f32')
+        if self.vocoder_precision not in ('f32', 'f16'):
+            raise ValueError(f"vocoder_precision must be 'f32' or 'f16', got {self.vocoder_precision!r}")
 
     @staticmethod
     def load_engine(path, device=0, speaker_embedding_dim=0, **kwargs):
@@ -128,7 +133,7 @@ class HipRuntime(Runtime):
             prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0))
 
     # ------------------------------------------------------------------ WaveGlow.infer (waveglow_arch.py:244-306)
-    def waveglow_infer(self, mel, z=None, sigma=1.0, deterministic=False, seed=None, **_ignored):
+    def waveglow_infer(self, mel, z=None, sigma=1.0, deterministic=False, seed=None, precision=None, **_ignored):
         dev = _is_torch_cuda(mel)
         if not dev:
             mel = np.asarray(mel, dtype=np.float32)
@@ -146,7 +151,7 @@ class HipRuntime(Runtime):
             else:
                 rng = self._rng if seed is None else np.random.default_rng(seed)
                 z = rng.standard_normal((B, T * 32, 8)).astype(np.float32)
-        return self.engine.waveglow_infer(mel, z=z, sigma=float(sigma))
+        return self.engine.waveglow_infer(mel, z=z, sigma=float(sigma), precision=precision or self.vocoder_precision)
 
 
 _runtimes = {'hip': HipRuntime}
