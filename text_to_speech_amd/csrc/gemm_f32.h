@@ -128,7 +128,8 @@ enum { PIPE_REG = 0, PIPE_DMA = 1 };
 // epilogue stores works on 4-byte units, so an fp16 operand is described to the kernel in "float units": ld, k, kpad, ldb
 // are HALF the element counts and one 16-byte LDS fragment (4 float units) carries 8 halfs = the K = 16 slice of one
 // MFMA -- the DMA pipeline, the swizzle and the segment addressing are shared with the fp32 kernel.
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false>
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false,
+          int NBD = 3>
 __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmArgs g) {
     static_assert(!HALF || PIPE == PIPE_DMA, "fp16 operands use the LDS-DMA pipeline");
     constexpr int BM = WR * RT * 32;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     constexpr bool DMA = PIPE == PIPE_DMA;
     static_assert(!DMA || BK == 16, "the LDS-DMA image is laid out for 64-byte rows");
     constexpr int LDSK = DMA ? BK : BK + 4; // LDS row in floats: padded (144 B / 80 B) or swizzled 64 B
-    constexpr int NBUF = DMA ? 3 : 2;
+    constexpr int NBUF = DMA ? NBD : 2;     // DMA: NBD - 1 tiles in flight
     constexpr int TPR = BK / 4;             // threads (float4) per tile row
     constexpr int NT = WR * WC * 64;        // threads: 4 waves (one per SIMD) or 8 (two per SIMD, one block per CU)
     constexpr int RPP = NT / TPR;           // rows staged per pass of the block's threads
@@ -392,9 +393,9 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 
     if (nSeq > 0) enter_segment();
     if constexpr (DMA) {
-        // Three LDS buffers.  Step t: issue tile t+2's DMA into the buffer read at step t-1 (every wave has passed the
-        // barrier that ended that step), run tile t's MFMAs, then wait until all but the newest tile's DMA have landed
-        // (counted vmcnt: tile t+1 is in LDS) and barrier.  No VGPR staging, no ds_write.
+        // NBUF (3 or 4) LDS buffers.  Step t: issue tile t+NBUF-1's DMA into the buffer read at step t-1 (every wave has
+        // passed the barrier that ended that step), run tile t's MFMAs, then wait until all but the newest NBUF-2 tiles'
+        // DMA have landed (counted vmcnt: tile t+1 is in LDS) and barrier.  No VGPR staging, no ds_write.
         constexpr int LT = PA + PB;                  // DMA instructions per tile per wave
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         auto dma_tile = [&](int buf) {
@@ -404,12 +405,15 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
             });
         };
-        dma_tile(0);
-        dma_tile(1);                                 // (no-op when there is a single tile)
-        if (nAll > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT) : "memory");
+        // prologue: NBUF - 1 tiles in flight (dma_tile is a no-op past the last tile, but still counts no instructions,
+        // so the counted waits below are only used while enough real tiles remain)
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b) dma_tile(b);
+        // wait for tile 0: at most min(nAll, NBUF - 1) - 1 newer tiles may stay in flight
+        if (nAll >= NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * LT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        int buf = 0, bufn = 2;                       // buffer of tile t, buffer for tile t+2
+        int buf = 0, bufn = NBUF - 1;                // buffer of tile t, buffer for tile t + NBUF - 1
 #ifndef TTS_ABL
 #define TTS_ABL 0
 #endif
@@ -421,12 +425,13 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                 for (int k8 = 0; k8 < BK / 8; ++k8) compute_chunk(buf, k8);
             }
             if (ABL != 1) {
-                if (t + 2 < nAll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT) : "memory");
+                // tile t + 1 must have landed: tiles t + 2 .. t + NBUF - 1 may stay in flight while they all exist
+                if (t + NBUF - 1 < nAll) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * LT) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            buf = buf == 2 ? 0 : buf + 1;
-            bufn = bufn == 2 ? 0 : bufn + 1;
+            buf = buf == NBUF - 1 ? 0 : buf + 1;
+            bufn = bufn == NBUF - 1 ? 0 : bufn + 1;
         }
     } else {
         // Two register stages: tile t+1 waits in one while tile t+2 is being fetched into the other (prefetch distance
@@ -519,12 +524,13 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         }
 }
 
-template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false>
+template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false,
+          int NBD = 3>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
     constexpr int LDSK = PIPE == PIPE_DMA ? BK : BK + 4;
-    constexpr int NBUF = PIPE == PIPE_DMA ? 3 : 2;
+    constexpr int NBUF = PIPE == PIPE_DMA ? NBD : 2;
     const int numNt = (g.N + BN - 1) / BN;
     const int numMt = (g.M + BM - 1) / BM;
     const int numMt8 = (numMt + 7) / 8 * 8;
@@ -542,7 +548,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
                 g.seg[i].ld != g.seg[0].ld)
                 return hipErrorInvalidValue;
     }
-    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE, HALF>;
+    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE, HALF, NBD>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -575,12 +581,15 @@ inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_g
 inline hipError_t gemm_wn_in_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 inline hipError_t gemm_wn_in0_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 // fp16-operand variants (activations and weights fp16 in HBM, fp32 accumulate): same tiles and pipeline
+#ifndef TTS_H_NBUF
+#define TTS_H_NBUF 3   // LDS buffers of that kernel (4 = three tiles in flight was measured no faster: 898 vs 855-885 us)
+#endif
 #ifndef TTS_H_WC
 #define TTS_H_WC 2     // fp16 in-layer GEMM: 8 waves, 256 x 256 block tile (the fp16 loop is bound by L2 -> LDS traffic)
 #endif
 inline hipError_t gemm_wn_in_h(const GemmArgs& g, bool t128, hipStream_t s) {
     if (!t128 && TTS_H_WC == 2)
-        return launch_gemm<TTS_WN_WR, 2, TTS_WN_RT, 4, TTS_WN_BK, 1, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s);
+        return launch_gemm<TTS_WN_WR, 2, TTS_WN_RT, 4, TTS_WN_BK, 1, TAG_WN_IN, WN_TAPS, PIPE_DMA, true, TTS_H_NBUF>(g, 1, s);
     return t128 ? launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s)
                 : launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s);
 }
