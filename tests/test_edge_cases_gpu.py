@@ -171,7 +171,7 @@ def test_tts_and_stream_facade_on_the_engine(gpu_engine):
     from text_to_speech_amd.waveglow import WaveGlow
     model = Tacotron2(HipRuntime('t', model='tacotron2', engine=gpu_engine, seed=0))
     voc = WaveGlow(HipRuntime('w', model='waveglow', engine=gpu_engine, seed=0))
-    (text, res), = tts('Hello there. General test!', model=model, vocoder=voc, max_length=6., max_text_length=-2)
+    res = tts('Hello there. General test!', model=model, vocoder=voc, max_length=6., max_text_length=-2, save=False)
     assert res['splitted'] == ['hello there.', 'general test!']
     frames = [m.shape[0] for m in res['mel']]
     assert frames == [6 * 12, 6 * 13]
@@ -183,6 +183,24 @@ def test_tts_and_stream_facade_on_the_engine(gpu_engine):
     for s in ('First sentence.', 'Second one.', None):
         q.put(s)
     got = []
-    stream(q, model=model, vocoder=voc, max_length=6., callbacks=[lambda r: got.append((r['text'], len(r['audio'])))])
+    stream(q, model=model, vocoder=voc, max_length=6., save=False,
+           callbacks=[lambda text, audio, **_: got.append((text, len(audio)))])
     assert [g[0] for g in got] == ['First sentence.', 'Second one.']
     assert got[0][1] == 6 * 15 * 256 and got[1][1] == 6 * 11 * 256
+
+
+def test_waveglow_large_batch_is_sliced_by_utterance(gpu_engine):
+    """B*T above one run's 31-bit addressing limit (~31.7 k frames): the library runs slices of whole utterances.
+    5 x 8000 frames -> slices of 3 + 2; an utterance of the second slice must equal its own batch-1 run."""
+    import torch
+    g = torch.Generator(device='cuda').manual_seed(5)
+    mel = torch.rand((5, 8000, 80), device='cuda', generator=g) * 12.7 - 11.5
+    z = torch.randn((5, 8000 * 32, 8), device='cuda', generator=g)
+    full = gpu_engine.waveglow_infer(mel, z=z)
+    assert full.shape == (5, 8000 * 256) and bool(torch.isfinite(full).all())
+    single = gpu_engine.waveglow_infer(mel[4:5].contiguous(), z=z[4:5].contiguous())
+    assert float((single[0] - full[4]).double().pow(2).mean().sqrt()) <= 5e-6
+    del full, single, mel, z
+    torch.cuda.empty_cache()
+    with pytest.raises(Exception, match='windowed inference'):
+        gpu_engine.waveglow_infer(np.zeros((1, 31745, 80), np.float32))

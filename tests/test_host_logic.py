@@ -73,14 +73,15 @@ def test_waveglow_float_win_len():
 
 # ------------------------------------------------------------------ H2: Tacotron2 wrapper
 class FakeSynth:
-    def __init__(self, lengths_seq):
+    def __init__(self, lengths_seq, default=50):
         self.lengths_seq = list(lengths_seq)
+        self.default = default
         self.calls = []
 
     def __call__(self, inputs, max_length=None, **kwargs):
         tok = inputs[0] if isinstance(inputs, tuple) else inputs
         self.calls.append((np.asarray(tok).copy(), max_length, kwargs))
-        n = self.lengths_seq.pop(0) if self.lengths_seq else 50
+        n = self.lengths_seq.pop(0) if self.lengths_seq else self.default
         T = 400
         mel = np.zeros((1, T, 80), np.float32)
         mel[0, :, 0] = np.arange(T)
@@ -128,10 +129,64 @@ def test_stream_consumes_queue_in_order():
     for s in ['first sentence to say.', 'second sentence to say.', None]:
         q.put(s)
     got = []
-    Tacotron2(synth).stream(q, vocoder=WaveGlow(FakeVocoder()), callbacks=[lambda r: got.append(r['text'])])
+    res = Tacotron2(synth).stream(q, vocoder=WaveGlow(FakeVocoder()), save=False,
+                                  callbacks=[lambda text, **_: got.append(text)])
+    assert res == []                                            # stream = predict(return_results=False)
     # two warm-up calls ('hello 64', 'hello 128': tacotron2.py:354-356) precede the stream
     assert [c[2].get('padding_multiple') for c in synth.calls[:2]] == [64, 128]
     assert got == ['first sentence to say.', 'second sentence to say.']
+
+
+def test_predict_saves_audio_and_map_json_and_reuses_the_cache(tmp_path):
+    """get_inference_callbacks + predicted-map semantics (tacotron2.py:130-132,227-241,276-352; file_saver.py)."""
+    import json
+    from scipy.io import wavfile
+    from text_to_speech_amd.tacotron2 import Tacotron2, tts
+    from text_to_speech_amd.waveglow import WaveGlow
+    d = str(tmp_path / 'out')
+    synth = FakeSynth([], default=100)
+    model, voc = Tacotron2(synth), WaveGlow(FakeVocoder())
+    t1, t2 = 'Hello world, this is a test.', 'Another sentence to synthesize.'
+    res = model.predict([t1, {'text': t2}], vocoder=voc, directory=d)
+    # a JSON saver is active -> predict returns the `predicted` entries (audio = file name), not the raw outputs
+    assert [r['text'] for r in res] == [t1, t2]
+    assert res[0]['audio'] == str(tmp_path / 'out' / 'audios' / 'audio-0.wav')
+    assert res[1]['audio'].endswith('audio-1.wav') and set(res[0]) == {'text', 'cleaned', 'splitted', 'rate', 'time', 'audio'}
+    rate, wav = wavfile.read(res[0]['audio'])
+    assert rate == 22050 and wav.dtype == np.int16 and wav.shape == (100 * 256,)
+    m = json.load(open(tmp_path / 'out' / 'map.json'))
+    assert list(m) == [t1, t2] and m[t1]['audio'] == res[0]['audio'] and m[t2]['splitted'] == ['another sentence to synthesize.']
+    # second run on a fresh model object: entries come from map.json, the synthesizer is not called, nothing is rewritten
+    synth2 = FakeSynth([], default=100)
+    seen = []
+    res2 = Tacotron2(synth2).predict(t1, vocoder=voc, directory=d, post_processing=lambda text, **kw: seen.append((text, sorted(kw))))
+    assert synth2.calls == [] and res2 == [m[t1]] and seen[0][0] == t1 and 'audio' in seen[0][1]
+    assert sorted(p.name for p in (tmp_path / 'out' / 'audios').iterdir()) == ['audio-0.wav', 'audio-1.wav']
+    # overwrite=True re-synthesizes but keeps the entry's file name (file_saver.py:107-110)
+    res3 = Tacotron2(synth2).predict(t1, vocoder=voc, directory=d, overwrite=True)
+    assert len(synth2.calls) == 1 and res3[0]['audio'] == res[0]['audio']
+    # a new text continues the numbering from the files on disk (file_saver.py:70-72)
+    res4 = Tacotron2(synth2).predict('A third one for the index.', vocoder=voc, directory=d)
+    assert res4[0]['audio'].endswith('audio-2.wav')
+    # no vocoder: mels are saved instead (save_mel defaults to save and vocoder is None)
+    res5 = Tacotron2(FakeSynth([], default=100)).predict('Only the spectrogram.', directory=str(tmp_path / 'mels_only'))
+    mel = np.load(res5[0]['mel'])
+    assert mel.shape == (100, 80) and 'audio' not in res5[0]
+    # save=False: nothing on disk, raw outputs come back; tts() unwraps a single text (models/tts/__init__.py:76-77)
+    out = tts(t1, model=model, vocoder=voc, save=False)
+    assert isinstance(out, dict) and out['audio'].shape == (100 * 256,) and out['mel'][0].shape == (100, 80)
+    outs = tts([t1, t2], model=model, vocoder=voc, save=False)
+    assert isinstance(outs, list) and len(outs) == 2
+
+
+def test_callbacks_failures_are_logged_not_raised(caplog):
+    from text_to_speech_amd.callbacks import FunctionCallback, QueueCallback, apply_callbacks
+    q = queue.Queue()
+
+    def boom(**_):
+        raise RuntimeError('nope')
+    apply_callbacks([FunctionCallback(boom), QueueCallback(q)], {'text': 'a'}, {'audio': 1})
+    assert q.get_nowait() == {'text': 'a'} and 'nope' in caplog.text
 
 
 # ------------------------------------------------------------------ text front-end

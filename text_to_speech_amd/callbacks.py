@@ -1,0 +1,227 @@
+"""Inference callbacks: result savers (`audio-{i}.wav`, `mel-{i}.npy`, `map.json`), function / queue hand-off.
+
+Host-side counterpart of /root/reference/utils/callbacks, with the behaviour
+`Tacotron2.infer` / `predict` rely on:
+  * a callback is called as `cb(infos, output)`: `infos` is the JSON-able entry of the `predicted` map (mutated in place:
+    savers record the file they wrote under their key), `output` the full result dict (callback.py:32-44);
+  * file savers number their files by counting what already matches the pattern on first use, then increment
+    (file_saver.py:63-76); an entry that already holds a file name is not written again (:104-110);
+  * `JSONSaver` stores `infos` under `infos[primary_key]` in the shared map and rewrites the json file (:167-193);
+  * `apply_callbacks(..., save=False)` skips the file savers (used when a cached entry is replayed, __init__.py:31-47)
+    and never lets a failing callback break inference: the error is logged.
+Differences: audio is written as 16-bit PCM `.wav` by default (no mp3 encoder in this image; pass `save_fn` to change it);
+players / displayers (displayer.py) are out of scope.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import logging
+import os
+import re
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+_INDEX_RE = re.compile(r'\{i?(:\d{2}d)?\}')
+
+
+def _to_numpy(x):
+    return x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
+
+
+def to_json(x):
+    """JSON-able copy of an `infos` entry (numpy scalars / arrays -> python)."""
+    if isinstance(x, dict):
+        return {str(k): to_json(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [to_json(v) for v in x]
+    if isinstance(x, np.generic):
+        return x.item()
+    if isinstance(x, np.ndarray) or hasattr(x, 'detach'):
+        return _to_numpy(x).tolist()
+    return x
+
+
+def write_wav(filename, audio, rate=22050):
+    """float waveform in [-1, 1] (clipped) -> 16-bit PCM wav."""
+    from scipy.io import wavfile
+    a = np.clip(_to_numpy(audio).astype(np.float32).reshape(-1), -1.0, 1.0)
+    wavfile.write(filename, int(rate), np.round(a * 32767.0).astype(np.int16))
+
+
+class Callback:
+    def __init__(self, name=None, cond=None, initializer=None, **_):
+        self.name = name or self.__class__.__name__
+        self.cond = cond
+        self.initializer = initializer
+        self.built = False
+
+    def __repr__(self):
+        return '<{}>'.format(self.__class__.__name__)
+
+    def build(self):
+        self.built = True
+
+    def __call__(self, infos, output, **kwargs):
+        if self.cond is not None and not self.cond(**output):
+            return None
+        if self.initializer:
+            for k, fn in self.initializer.items():
+                if k not in output:
+                    output[k] = fn(**output)
+        if not self.built:
+            self.build()
+        return self.apply(infos=infos, output=output, **kwargs)
+
+    def apply(self, infos, output, **kwargs):
+        raise NotImplementedError()
+
+    def join(self):
+        pass
+
+
+class FileSaver(Callback):
+    def __init__(self, key, file_format, *, data_key=None, additional_keys=None, index=-1, index_key=None,
+                 save_fn=None, name=None, **kwargs):
+        super().__init__(name=name or 'saving {}'.format(key), **kwargs)
+        self.key = key
+        self.data_key = data_key or key
+        self.file_format = file_format
+        self.additional_keys = additional_keys or []
+        self.index = index
+        self.index_key = index_key
+        self.use_index = _INDEX_RE.search(file_format) is not None
+        self.save_fn = save_fn
+
+    def build(self):
+        super().build()
+        directory = os.path.dirname(self.file_format)
+        if directory:
+            os.makedirs(directory, exist_ok=True)
+
+    def _get_index(self, output):
+        if not self.use_index:
+            return -1
+        if self.index_key in output:
+            return output[self.index_key]
+        if self.index == -1:
+            self.index = len(glob.glob(_INDEX_RE.sub('*', self.file_format)))
+        idx = self.index
+        self.index += 1
+        return idx
+
+    def _format_filename(self, infos, output):
+        idx = self._get_index(output)
+        fields = {k: v for k, v in output.items() if isinstance(v, (str, int, float))}
+        if '{basename}' in self.file_format and 'basename' not in fields:
+            fields['basename'] = '.'.join(os.path.basename(infos['filename']).split('.')[:-1])
+        fields.pop('i', None)
+        return self.file_format.format(idx, i=idx, **fields)
+
+    def apply(self, infos, output, **_):
+        if isinstance(output.get(self.key, None), str):       # already a file name: just remember it
+            if self.key not in infos:
+                infos[self.key] = output[self.key]
+            return None
+        if infos.get(self.key, None) is None:
+            infos[self.key] = self._format_filename(infos, output)
+        self.save(infos[self.key], output[self.data_key], **{k: output[k] for k in self.additional_keys})
+        return infos[self.key]
+
+    def save(self, filename, data, **kwargs):
+        self.save_fn(filename, data, **kwargs)
+
+
+class AudioSaver(FileSaver):
+    def __init__(self, key='audio', file_format='audio-{}.wav', **kwargs):
+        kwargs.setdefault('save_fn', write_wav)
+        kwargs['additional_keys'] = ['rate']
+        super().__init__(key, file_format, **kwargs)
+
+
+class SpectrogramSaver(FileSaver):
+    def __init__(self, key='mel', file_format='mel-{}.npy', **kwargs):
+        kwargs.setdefault('save_fn', lambda filename, data: np.save(filename, data))
+        super().__init__(key, file_format, **kwargs)
+
+    def save(self, filename, data):
+        if isinstance(data, list):                                  # one mel per sentence part -> one [T, 80] file
+            data = np.concatenate([_to_numpy(d) for d in data], axis=0)
+        else:
+            data = _to_numpy(data)
+        return super().save(filename, data)
+
+
+class JSONSaver(FileSaver):
+    def __init__(self, data, filename, primary_key, *, name='saving json', **kwargs):
+        super().__init__(None, filename, name=name, **kwargs)
+        self.data = data
+        self.primary_key = primary_key
+
+    def __repr__(self):
+        return '<{} file={}>'.format(self.__class__.__name__, self.file_format)
+
+    def apply(self, infos, output, **_):
+        if self.primary_key not in infos:
+            return None
+        key = infos[self.primary_key]
+        if not isinstance(key, str):
+            return None
+        self.data[key] = to_json(infos)
+        self.save()
+        return key
+
+    def save(self):
+        tmp = self.file_format + '.tmp'
+        with open(tmp, 'w', encoding='utf-8') as f:
+            json.dump(self.data, f, indent=4)
+        os.replace(tmp, self.file_format)
+
+
+class FunctionCallback(Callback):
+    def __init__(self, fn, name=None, include_outputs=True, **kwargs):
+        super().__init__(name=name or getattr(fn, '__name__', fn.__class__.__name__), **kwargs)
+        self.fn = fn
+        self.include_outputs = include_outputs
+
+    def apply(self, infos, output, **kwargs):
+        kwargs.update(infos)
+        if self.include_outputs:
+            kwargs.update(output)
+        return self.fn(**kwargs)
+
+
+class QueueCallback(Callback):
+    def __init__(self, queue, name='queue', **kwargs):
+        super().__init__(name=name, **kwargs)
+        self.queue = queue
+
+    def apply(self, infos, output, **kwargs):
+        kwargs.update(infos)
+        return self.queue.put(kwargs)
+
+
+def load_json(filename, default=None):
+    if not os.path.exists(filename):
+        return default
+    with open(filename, 'r', encoding='utf-8') as f:
+        return json.load(f)
+
+
+def apply_callbacks(callbacks, infos, output, save=True, **kwargs):
+    """Runs every callback; returns the key `JSONSaver` stored the entry under (or None)."""
+    if not callbacks:
+        return None
+    entry = None
+    for callback in callbacks:
+        if isinstance(callback, FileSaver) and not save:
+            continue
+        try:
+            res = callback(infos, output, **kwargs)
+            if isinstance(callback, JSONSaver):
+                entry = res
+        except Exception as exc:                                     # noqa: BLE001 -- mirrors the reference: log and go on
+            logger.error('- An exception occured while calling %s : %s', callback, exc)
+    return entry

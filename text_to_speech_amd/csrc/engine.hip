@@ -220,8 +220,20 @@ static int waveglow_infer_impl(tts_hip_engine* e, const float* mel, int B, int T
     } else if (mem != TTS_HIP_MEM_DEVICE) {
         return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: bad mem kind %d", mem);
     }
-    int rc = waveglow_run(e, d_mel, B, T, d_z, sigma, d_out, precision);
-    if (rc) return rc;
+    // One run addresses its activations with 31-bit byte offsets (<= ~32 k frames).  Utterances are independent, so a
+    // larger batch is processed in slices of whole utterances; a single utterance above the limit is refused (the Python
+    // wrapper's windowed inference, models/tts/waveglow.py:114-142, is the reference's own answer to long mels).
+    constexpr int kMaxFramesPerRun = 31744;
+    if (T > kMaxFramesPerRun)
+        return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: T = %d frames exceeds one run's limit (%d); use windowed inference",
+                       T, kMaxFramesPerRun);
+    const int chunkB = kMaxFramesPerRun / T;
+    for (int b0 = 0; b0 < B; b0 += chunkB) {
+        const int nb = B - b0 < chunkB ? B - b0 : chunkB;
+        int rc = waveglow_run(e, d_mel + (size_t)b0 * T * 80, nb, T, d_z ? d_z + (size_t)b0 * T * 32 * 8 : nullptr, sigma,
+                              d_out + (size_t)b0 * T * 256, precision);
+        if (rc) return rc;
+    }
     if (mem == TTS_HIP_MEM_HOST)
         HIPCHK(e, hipMemcpyAsync(audio, d_out, n_out * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));

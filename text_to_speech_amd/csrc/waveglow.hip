@@ -195,8 +195,8 @@ __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __
 // Folded skip/end conv + affine inverse + inverse 1x1 conv (+ early-z prepend), RPW positions per wave.
 //   out[m][o] = sum_layer sum_c acts[layer][m][c] * wfold[layer][o][c] + bfold[o]          (waveglow_arch.py:129-141)
 //   audio_1 = (audio_1 - b) / exp(s); audio = [audio_0, audio_1] @ inv; prepend sigma * z_early   (:284-304)
-// Lane l owns channels 8l..8l+7; per layer the lane's 8x8 slice of wfold sits in registers and is reused for the RPW
-// rows; the RPW*8 partial sums are reduced with the lane-halving exchange (63 shuffles for 64 values).
+// Lane l owns channels 4l..4l+3 and 256+4l..256+4l+3 (every wave-level load is one contiguous 1 KiB run); per layer
+// the lane's 8x8 slice of wfold sits in registers and is reused for the RPW rows; the RPW*8 partial sums are reduced with the lane-halving exchange (63 shuffles for 64 values).
 constexpr int RPW = 8;
 template <bool HALF>
 __global__ __launch_bounds__(256) void wn_end_fold_kernel(const void* __restrict__ acts_v, long long layer_stride,
@@ -216,23 +216,25 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const void* __restrict
     for (int i = 0; i < RPW * 8; ++i) acc[i] = 0.f;
     for (int layer = 0; layer < 8; ++layer) {
         f32x4 w0[8], w1[8], a0[RPW], a1[RPW];
-        const float* wl = wfold + ((long long)layer * 8) * C + lane * 8;
+        const float* wl = wfold + ((long long)layer * 8) * C + lane * 4;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             w0[o] = *reinterpret_cast<const f32x4*>(wl + o * C);
-            w1[o] = *reinterpret_cast<const f32x4*>(wl + o * C + 4);
+            w1[o] = *reinterpret_cast<const f32x4*>(wl + o * C + C / 2);
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const long long m = m0 + r < M ? m0 + r : M - 1;       // clamp: tail rows are computed but never stored
             if constexpr (HALF) {
-                const f16x8 hv = *reinterpret_cast<const f16x8*>((const _Float16*)acts_v + layer * layer_stride + m * C + lane * 8);
-                a0[r] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                a1[r] = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+                const _Float16* al = (const _Float16*)acts_v + layer * layer_stride + m * C + lane * 4;
+                const f16x4 h0 = *reinterpret_cast<const f16x4*>(al);
+                const f16x4 h1 = *reinterpret_cast<const f16x4*>(al + C / 2);
+                a0[r] = f32x4{(float)h0[0], (float)h0[1], (float)h0[2], (float)h0[3]};
+                a1[r] = f32x4{(float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]};
             } else {
-                const float* al = (const float*)acts_v + layer * layer_stride + lane * 8;
+                const float* al = (const float*)acts_v + layer * layer_stride + lane * 4;
                 a0[r] = *reinterpret_cast<const f32x4*>(al + m * C);
-                a1[r] = *reinterpret_cast<const f32x4*>(al + m * C + 4);
+                a1[r] = *reinterpret_cast<const f32x4*>(al + m * C + C / 2);
             }
         }
 #pragma unroll
