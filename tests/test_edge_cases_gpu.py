@@ -204,3 +204,24 @@ def test_waveglow_large_batch_is_sliced_by_utterance(gpu_engine):
     torch.cuda.empty_cache()
     with pytest.raises(Exception, match='windowed inference'):
         gpu_engine.waveglow_infer(np.zeros((1, 31745, 80), np.float32))
+
+
+def test_waveglow_exact_halo_tiling_matches_single_run(gpu_engine):
+    """WaveGlow.infer_exact: time tiles with a 100-frame halo reproduce the one-run samples (receptive field of 12 flows =
+    3060 groups = 95.6 frames + upsampling window); the reference's win_len/hop_len windowing is only approximate."""
+    from text_to_speech_amd.runtime import HipRuntime
+    from text_to_speech_amd.waveglow import WaveGlow
+    voc = WaveGlow(HipRuntime('w', model='waveglow', engine=gpu_engine, seed=0))
+    rng = np.random.default_rng(9)
+    mel = rng.uniform(-11.5, 1.2, (1, 460, 80)).astype(np.float32)
+    z = rng.standard_normal((1, 460 * 32, 8)).astype(np.float32)
+    full = gpu_engine.waveglow_infer(mel, z=z)
+    tiled = voc.infer_exact(mel, tile_frames=130, z=z)
+    assert tiled.shape == full.shape == (1, 460 * 256)
+    d = np.abs(tiled - full).max()
+    print('exact tiling max abs diff', d)
+    assert d <= 2e-6                      # same arithmetic per sample; only the tile kernels (128/256 rows) may differ
+    # context does matter: a 2-frame halo is shorter than even one flow's reach (255 groups = 8 frames)
+    from text_to_speech_amd.waveglow import infer_tiled
+    short = infer_tiled(voc.compiled_infer, mel, z=z, tile_frames=130, halo=2)
+    assert np.abs(short - full).max() > 1e-4

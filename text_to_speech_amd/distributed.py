@@ -117,3 +117,51 @@ def synthesize_sharded(tokens, synth_fn, speaker=None, src: int = 0, device=None
     else:
         audio, counts = np.zeros((0, 1), np.float32), np.zeros((0,), np.int64)
     return gather_audio(audio, counts, parts, dst=src, device=device)
+
+
+def vocode_long_sharded(mel, vocode_fn, z=None, tile_frames=2048, halo=None, src: int = 0, device=None):
+    """One long utterance over all ranks (SURVEY.md section 8e "within one long utterance"): rank `src` passes
+    mel [1, T, 80] (+ z [1, T*32, 8]); it is broadcast, every rank vocodes the time tiles r, r + world, ... with an exact
+    receptive-field halo (text_to_speech_amd.waveglow.infer_tiled) and rank `src` receives the [T*256] waveform (others
+    None).  `vocode_fn(mel, z=None) -> audio [1, T*256]`.  Communication: one broadcast in, one gather out."""
+    from .waveglow import HALO_FRAMES, infer_tiled, tile_plan
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = _device(device)
+    halo = HALO_FRAMES if halo is None else halo
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    if rank == src:
+        mel = torch.as_tensor(np.asarray(mel), dtype=torch.float32)
+        if mel.dim() == 2:
+            mel = mel[None]
+        meta = torch.tensor([mel.shape[1], 0 if z is None else 1], dtype=torch.int64, device=device)
+    dist.broadcast(meta, src)
+    T, has_z = int(meta[0]), bool(meta[1])
+    mel_d = mel.to(device) if rank == src else torch.zeros((1, T, 80), dtype=torch.float32, device=device)
+    dist.broadcast(mel_d, src)
+    z_d = None
+    if has_z:
+        z_d = (torch.as_tensor(np.asarray(z), dtype=torch.float32).to(device) if rank == src
+               else torch.zeros((1, T * 32, 8), dtype=torch.float32, device=device))
+        dist.broadcast(z_d, src)
+    plan = tile_plan(T, tile_frames, halo)
+    mine = list(range(rank, len(plan), world))
+    on_gpu = device.type == 'cuda'
+    m_in = mel_d if on_gpu else mel_d.numpy()
+    z_in = None if z_d is None else (z_d if on_gpu else z_d.numpy())
+    pieces = infer_tiled(vocode_fn, m_in, z=z_in, tile_frames=tile_frames, halo=halo, tiles=mine)
+    # equal-sized padded contributions -> one gather
+    n_max = max(1, (len(plan) + world - 1) // world)
+    buf = torch.zeros((n_max, tile_frames * 256), dtype=torch.float32, device=device)
+    for row, (start, stop, a) in enumerate(pieces):
+        buf[row, :(stop - start) * 256] = torch.as_tensor(a, dtype=torch.float32).reshape(-1).to(device)
+    gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == src else None
+    dist.gather(buf, gathered, dst=src)
+    if rank != src:
+        return None
+    out = np.zeros((T * 256,), np.float32)
+    for r in range(world):
+        g = gathered[r].cpu().numpy()
+        for row, i in enumerate(range(r, len(plan), world)):
+            start, stop, _, _ = plan[i]
+            out[start * 256:stop * 256] = g[row, :(stop - start) * 256]
+    return out

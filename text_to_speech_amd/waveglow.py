@@ -27,6 +27,50 @@ def _to_numpy(x):
     return x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
 
 
+# ---- exact time tiling ------------------------------------------------------------------------------------------------
+# WaveGlow inference is feed-forward with a finite receptive field: per flow the 8 dilated k=3 convs reach
+# 1 + 2 + ... + 128 = 255 groups (of 8 samples) to each side, 12 flows -> 3060 groups = 95.6 mel frames, plus the 4-frame
+# window of the upsampling transposed conv (SURVEY.md section 8e).  A tile computed from its frames plus HALO_FRAMES of
+# real context on each side therefore reproduces the full-sequence samples of its core region exactly; only samples whose
+# receptive field crosses an artificial tile edge differ, and those all lie inside the discarded halo.  (The reference's
+# own windowing, `infer(win_len=...)` below, is approximate: it discards half of a 64-frame overlap.)
+HALO_FRAMES = 100
+
+
+def tile_plan(n_frames, tile_frames, halo=HALO_FRAMES):
+    """[(start, stop, lo, hi)]: core frames [start, stop) are taken from a run over mel[lo:hi]."""
+    if tile_frames <= 0:
+        raise ValueError('tile_frames must be positive')
+    plan = []
+    for start in range(0, n_frames, tile_frames):
+        stop = min(n_frames, start + tile_frames)
+        plan.append((start, stop, max(0, start - halo), min(n_frames, stop + halo)))
+    return plan
+
+
+def infer_tiled(compiled_infer, mel, z=None, tile_frames=4096, halo=HALO_FRAMES, tiles=None, **kwargs):
+    """Exact vocoding of a long mel [B, T, 80] in time tiles; `tiles` (indices into tile_plan) restricts the work to a
+    subset (multi-GPU sharding of one utterance) -- the result then is a list of (start, stop, audio [B, (stop-start)*256])."""
+    T = mel.shape[1]
+    plan = tile_plan(T, tile_frames, halo)
+    chosen = range(len(plan)) if tiles is None else tiles
+    out = []
+    for i in chosen:
+        start, stop, lo, hi = plan[i]
+        zz = None if z is None else z[:, lo * 32:hi * 32]
+        if _is_torch_cuda(mel):
+            sub = mel[:, lo:hi].contiguous()
+            zz = None if zz is None else zz.contiguous()
+        else:
+            sub = np.ascontiguousarray(mel[:, lo:hi])
+        a = compiled_infer(sub, z=zz, **kwargs)
+        out.append((start, stop, a[:, (start - lo) * 256:(stop - lo) * 256]))
+    if tiles is not None:
+        return out
+    parts = [_to_numpy(a) for _, _, a in out]
+    return np.concatenate(parts, axis=1)
+
+
 class WaveGlow:
     """`vocoder(mel, **kwargs)` object accepted by `Tacotron2.infer(..., vocoder=...)`."""
     rate = 22050
@@ -100,3 +144,12 @@ class WaveGlow:
         return np.concatenate(audio, axis=-1)
 
     __call__ = infer
+
+    def infer_exact(self, mel, *, tile_frames=4096, z=None, **kwargs):
+        """Long-form vocoding without the approximation of `infer(win_len=...)`: halo tiling, bit-for-bit the samples of
+        one run over the whole mel (which one C-ABI call only accepts up to ~31.7 k frames)."""
+        if isinstance(mel, str):
+            mel = np.load(mel)
+        if len(mel.shape) == 2:
+            mel = mel[None]
+        return infer_tiled(self.compiled_infer, mel, z=z, tile_frames=tile_frames, **kwargs)
