@@ -475,20 +475,20 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if constexpr (CT % 2 == 0) {
         if (g.mode == EPI_GATE) {
-            // a wave's CT*32 columns hold CT*16 tanh pre-activations followed by the matching sigmoid pre-activations
-            // (weight rows are permuted at load time in groups of CT*32); output channel = group * CT*16 + local column.
-            constexpr int H = CT / 2;
+            // weight rows are permuted at load time in groups of 64: 32 tanh pre-activations followed by the 32 matching
+            // sigmoid pre-activations, so MFMA column tiles (2q, 2q + 1) of a wave pair up; output channel =
+            // (first column of the pair / 64) * 32 + lane column.
             float* out = outp;
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int j = 0; j < H; ++j) {
-                    const int ch = (nt * WC + wc) * (CT * 16) + j * 32 + li;
+                for (int q = 0; q < CT / 2; ++q) {
+                    const int ch = ((n0 + wc * CT * 32) / 64 + q) * 32 + li;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
                         if (m < g.M) {
-                            const float gv = gate_tanh_sigmoid(acc[i][j][r], acc[i][j + H][r]);
+                            const float gv = gate_tanh_sigmoid(acc[i][2 * q][r], acc[i][2 * q + 1][r]);
                             if constexpr (HALF) g.out0h[(long long)m * g.ld0h + ch] = (_Float16)gv;
                             else out[(long long)m * g.ld0 + ch] = gv;
                         }
@@ -580,6 +580,13 @@ inline hipError_t gemm_wn_in(const GemmArgs& g, hipStream_t s) { return launch_g
 // 128-row-tile variants: used when padding the phase blocks to 256 rows would waste more work (e.g. batch 1)
 inline hipError_t gemm_wn_in_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
 inline hipError_t gemm_wn_in0_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+// 128 x 64 tiles for short utterances (a few hundred frames at batch 1): twice the blocks, so that every CU gets work
+inline hipError_t gemm_wn_in_64(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_in0_64(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_res_64(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_in_64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
+inline hipError_t gemm_wn_in0_64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
+inline hipError_t gemm_wn_res_64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_RES_SKIP, 0, PIPE_DMA, true>(g, 1, s); }
 // fp16-operand variants (activations and weights fp16 in HBM, fp32 accumulate): same tiles and pipeline
 #ifndef TTS_H_NBUF
 #define TTS_H_NBUF 3   // LDS buffers of that kernel (4 = three tiles in flight was measured no faster: 898 vs 855-885 us)

@@ -46,7 +46,8 @@ constexpr int KMEL = 4 * 80;  // folded conditioning: 4 mel frames x 80 channels
 constexpr int NPH = 32;       // phases (sample groups per mel frame)
 
 // dst[n][koff + k] = src[k * src_ld + perm(n)]  for k < K   (Keras [K][N] kernel slice -> Bt rows)
-// perm: 0 identity; 1 WN gate interleave (per 128-row tile: 64 tanh channels then their 64 sigmoid partners)
+// perm: 0 identity; 1 WN gate interleave (per group of 64 rows: 32 tanh channels then their 32 sigmoid partners, so a
+//       wave's pair of adjacent 32-column MFMA tiles holds matching pre-activations for every N tile >= 64 columns)
 // taps > 1: src is [taps][K/taps][N] and the K axis of dst is tap-interleaved in chunks of `bk`:
 //   dst k = (c / bk) * taps * bk + tap * bk + c % bk     (matches gemm_f32_kernel's NI = taps tile order)
 __global__ void pack_bt_kernel(const float* __restrict__ src, int K, int src_ld, float* __restrict__ dst, int N,
@@ -61,8 +62,8 @@ __global__ void pack_bt_kernel(const float* __restrict__ src, int K, int src_ld,
     }
     int sn = n;
     if (perm == 1) {
-        const int tile = n >> 7, q = n & 127;
-        sn = q < 64 ? tile * 64 + q : C + tile * 64 + (q - 64);
+        const int grp = n >> 6, q = n & 63;
+        sn = q < 32 ? grp * 32 + q : C + grp * 32 + (q - 32);
     }
     dst[(long long)n * ldb + koff + kd] = src[(long long)k * src_ld + sn];
 }
@@ -73,8 +74,8 @@ __global__ void pack_bias_kernel(const float* __restrict__ a, const float* __res
     if (n >= N) return;
     int sn = n;
     if (perm == 1) {
-        const int tile = n >> 7, q = n & 127;
-        sn = q < 64 ? tile * 64 + q : C + tile * 64 + (q - 64);
+        const int grp = n >> 6, q = n & 63;
+        sn = q < 32 ? grp * 32 + q : C + grp * 32 + (q - 32);
     }
     dst[n] = a[sn] + (b ? b[sn] : 0.f);
 }
@@ -599,6 +600,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     const bool tile128 = pr128 * 1.05 < pr256;
     const int PR = tile128 ? pr128 : pr256;
     const long long M = (long long)NPH * PR;                     // phase-major rows (incl. padding)
+    // short utterances: 128 x 128 tiles would leave block slots (3 per CU) empty -> 128 x 64 tiles, twice the blocks
+    const bool tile64 = tile128 && (M / 128) * 8 < 768;
     if ((double)M * C * 4.0 >= 2147483648.0 - 65536.0)
         return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: B*T = %d frames exceeds one call's limit (~32000)", BT);
     HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
@@ -672,8 +675,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 g.out0 = acts_i;
                 g.ld0 = C;
                 timing_begin(e, i == 0 ? 3 : 0);
-                if (i == 0) HIPCHK(e, tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
-                else HIPCHK(e, tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
+                if (i == 0) HIPCHK(e, tile64 ? gemm_wn_in0_64(g, st) : tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
+                else HIPCHK(e, tile64 ? gemm_wn_in_64(g, st) : tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
                 timing_end(e);
                 if (i < 7) {             // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
                     GemmArgs r{};
@@ -692,7 +695,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.ld0 = C;
                     r.acc0 = 1;
                     timing_begin(e, 1);
-                    HIPCHK(e, gemm_wn_res_skip(r, st));
+                    HIPCHK(e, tile64 ? gemm_wn_res_64(r, st) : gemm_wn_res_skip(r, st));
                     timing_end(e);
                 }
             } else {
@@ -717,7 +720,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 g.out0h = acts_i;
                 g.ld0h = C;
                 timing_begin(e, i == 0 ? 3 : 0);
-                HIPCHK(e, i == 0 ? gemm_wn_in0_h(g, tile128, st) : gemm_wn_in_h(g, tile128, st));
+                if (tile64) HIPCHK(e, i == 0 ? gemm_wn_in0_64h(g, st) : gemm_wn_in_64h(g, st));
+                else HIPCHK(e, i == 0 ? gemm_wn_in0_h(g, tile128, st) : gemm_wn_in_h(g, tile128, st));
                 timing_end(e);
                 if (i < 7) {
                     GemmArgs r{};
@@ -738,7 +742,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.out0h = x16;           // fp16 shadow = operand of the next layer's taps
                     r.ld0h = C;
                     timing_begin(e, 1);
-                    HIPCHK(e, gemm_wn_res_h(r, st));
+                    HIPCHK(e, tile64 ? gemm_wn_res_64h(r, st) : gemm_wn_res_h(r, st));
                     timing_end(e);
                 }
             }
