@@ -1,7 +1,7 @@
 """Probe: fp16-operand WaveGlow vs the exact fp32 path and the numpy oracle (error + speed)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from text_to_speech_amd import config, weights
 from text_to_speech_amd.engine import HipEngine
 from oracle import waveglow_ref

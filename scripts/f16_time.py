@@ -1,7 +1,7 @@
 """Kernel timings of the fp16 WaveGlow path at config 2 (uses TTS_HIP_LIBRARY if set)."""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from text_to_speech_amd import config, weights
 from text_to_speech_amd.engine import HipEngine

@@ -1,7 +1,7 @@
 """WaveGlow throughput vs utterance length at batch 1 (configs 1 / 5 run sentence by sentence)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from text_to_speech_amd import config, weights
 from text_to_speech_amd.engine import HipEngine

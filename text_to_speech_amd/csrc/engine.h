@@ -97,7 +97,6 @@ struct Tacotron2Dev {
     float* query_w = nullptr;           // [128][1024]
     float* memory_Bt = nullptr;         // [128][enc]
     float* value_w = nullptr;           // [128]
-    float* loc_conv = nullptr;          // [32][31][2]
     float* loc_dense = nullptr;         // [128][32]   (transposed)
     float* proj_w = nullptr;            // [81][1024 + enc]  (80 mel rows + gate row)
     float* proj_b = nullptr;            // [81]

@@ -59,14 +59,6 @@ __global__ void pack_lstm_kernel(const float* __restrict__ kernel, const float* 
     }
 }
 
-// dst[n][k] = src[k][n]   (Dense kernel [in][out] -> out-major rows)
-__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int N, int ldd) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)K * N) return;
-    const int n = (int)(idx / K), k = (int)(idx % K);
-    dst[(long long)n * ldd + k] = src[(long long)k * N + n];
-}
-
 // ------------------------------------------------------------------------------------------------ encoder kernels
 __global__ void embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, float* __restrict__ x,
                              uint8_t* __restrict__ mask, int n_rows, int vocab) {
@@ -273,7 +265,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
 #pragma unroll
         for (int q = 0; q < GSZ; ++q)
             if (q < P) xbuf[0][q] = *reinterpret_cast<const f32x4*>(xl + (q % NBT) * K + (q / NBT) * 256);
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int g = 0; g < G; ++g) {
             if (g + 1 < G) {
 #pragma unroll
@@ -313,8 +305,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
             const bool hi = (lane & m) != 0;
 #pragma unroll
             for (int i = 0; i < half; ++i) {
-                const float send = hi ? acc[i] : acc[i + half];
-                const float keep = hi ? acc[i + half] : acc[i];
+                float a_lo = acc[i], a_hi = acc[i + half];
+                // opaque copies: otherwise instcombine turns select(load, load) into a dynamically indexed load of the
+                // register array, which lowers to a compare/select chain over every element (seen for <7, 8>: 3.3 k extra VALU)
+                asm volatile("" : "+v"(a_lo), "+v"(a_hi));
+                const float send = hi ? a_lo : a_hi;
+                const float keep = hi ? a_hi : a_lo;
                 acc[i] = keep + __shfl_xor(send, m, 64);
             }
         }
@@ -372,8 +368,12 @@ __global__ __launch_bounds__(256) void query_kernel(const DecState* __restrict__
             const bool hi = (lane & m) != 0;
 #pragma unroll
             for (int i = 0; i < half; ++i) {
-                const float send = hi ? acc[i] : acc[i + half];
-                const float keep = hi ? acc[i + half] : acc[i];
+                float a_lo = acc[i], a_hi = acc[i + half];
+                // opaque copies: otherwise instcombine turns select(load, load) into a dynamically indexed load of the
+                // register array, which lowers to a compare/select chain over every element (seen for <7, 8>: 3.3 k extra VALU)
+                asm volatile("" : "+v"(a_lo), "+v"(a_hi));
+                const float send = hi ? a_lo : a_hi;
+                const float keep = hi ? a_hi : a_lo;
                 acc[i] = keep + __shfl_xor(send, m, 64);
             }
         }
@@ -608,8 +608,12 @@ __global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st,
             const bool hi = (lane & m) != 0;
 #pragma unroll
             for (int i = 0; i < half; ++i) {
-                const float send = hi ? acc[i] : acc[i + half];
-                const float keep = hi ? acc[i + half] : acc[i];
+                float a_lo = acc[i], a_hi = acc[i + half];
+                // opaque copies: otherwise instcombine turns select(load, load) into a dynamically indexed load of the
+                // register array, which lowers to a compare/select chain over every element (seen for <7, 8>: 3.3 k extra VALU)
+                asm volatile("" : "+v"(a_lo), "+v"(a_hi));
+                const float send = hi ? a_lo : a_hi;
+                const float keep = hi ? a_hi : a_lo;
                 acc[i] = keep + __shfl_xor(send, m, 64);
             }
         }

@@ -256,8 +256,12 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const void* __restrict
         const bool hi = (lane & msk) != 0;
 #pragma unroll
         for (int i = 0; i < half; ++i) {
-            const float send = hi ? acc[i] : acc[i + half];
-            const float keep = hi ? acc[i + half] : acc[i];
+            float a_lo = acc[i], a_hi = acc[i + half];
+            // opaque copies: otherwise instcombine turns select(load, load) into a dynamically indexed load of the
+            // register array, which lowers to a compare/select chain over every element (seen for <7, 8>: 3.3 k extra VALU)
+            asm volatile("" : "+v"(a_lo), "+v"(a_hi));
+            const float send = hi ? a_lo : a_hi;
+            const float keep = hi ? a_hi : a_lo;
             acc[i] = keep + __shfl_xor(send, msk, 64);
         }
     }
