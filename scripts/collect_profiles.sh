@@ -28,4 +28,7 @@ for b in 1 8; do
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/taco_b$b" -o taco -- \
         python3 "$root/scripts/run_taco.py" $b 256 > "$out/taco_b$b.txt" 2> "$out/taco_b$b.log"
 done
+# 5. HBM/L2 fetch bytes of the decoder-step kernels (weight streaming), batch 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/taco_pmc_b1" -o taco -- \
+    python3 "$root/scripts/run_taco.py" 1 64 > /dev/null 2> "$out/taco_pmc_b1.log"
 find "$out" -name "*.csv" | sort

@@ -74,6 +74,10 @@ for kn, cs in merged.items():
     if 'SQ_WAIT_ANY' in cs and 'SQ_WAVE_CYCLES' in cs:
         e['wait_any_frac'] = sum(cs['SQ_WAIT_ANY']) / max(1.0, sum(cs['SQ_WAVE_CYCLES']))
     summary['kernels'][kn[:120]] = e
+taco = counters('taco_pmc_b1')
+if taco:
+    summary['tacotron2_b1_fetch_KB_mean'] = {kn[:90]: sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE'])
+                                             for kn, cs in taco.items() if 'FETCH_SIZE' in cs and len(cs['FETCH_SIZE']) >= 32}
 json.dump(summary, open(os.path.join(dst, f'{tag}_pmc_counters.json'), 'w'), indent=1)
 print('wrote', f'{tag}_pmc_counters.json')
 for kn, e in summary['kernels'].items():
