@@ -225,3 +225,26 @@ def test_waveglow_exact_halo_tiling_matches_single_run(gpu_engine):
     from text_to_speech_amd.waveglow import infer_tiled
     short = infer_tiled(voc.compiled_infer, mel, z=z, tile_frames=130, halo=2)
     assert np.abs(short - full).max() > 1e-4
+
+
+def test_stream_overlap_two_engines_same_audio(gpu_engine, wg_weights, taco_weights):
+    """stream(overlap=True) with the vocoder on its own engine handle (second HIP stream on the same GPU) gives exactly the
+    audio of the sequential path: the two halves only exchange host arrays, and each engine is deterministic."""
+    from text_to_speech_amd.engine import HipEngine
+    from text_to_speech_amd.runtime import HipRuntime
+    from text_to_speech_amd.tacotron2 import Tacotron2
+    from text_to_speech_amd.waveglow import WaveGlow
+    eng2 = HipEngine(0)
+    eng2.load_state(wg_weights)
+    eng2.finalize()
+    model = Tacotron2(HipRuntime('t', model='tacotron2', engine=gpu_engine, seed=0))
+    voc_same = WaveGlow(HipRuntime('w', model='waveglow', engine=gpu_engine, seed=0))
+    voc_own = WaveGlow(HipRuntime('w2', model='waveglow', engine=eng2, seed=0))
+    texts = ['First sentence of the stream.', 'A second, slightly longer sentence follows.', 'Third.', 'And the last one.']
+    kw = dict(max_length=5., deterministic=True, save=False)
+    seq = model.predict(texts, vocoder=voc_same, **kw)
+    ovl = model.predict(texts, vocoder=voc_own, overlap=True, **kw)
+    assert [r['text'] for r in ovl] == texts
+    for a, b in zip(seq, ovl):
+        assert a['audio'].shape == b['audio'].shape and np.array_equal(a['audio'], b['audio'])
+    eng2.close()

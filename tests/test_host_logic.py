@@ -179,6 +179,47 @@ def test_predict_saves_audio_and_map_json_and_reuses_the_cache(tmp_path):
     assert isinstance(outs, list) and len(outs) == 2
 
 
+def test_overlapped_stream_keeps_order_overlaps_work_and_propagates_errors():
+    """stream(overlap=True): Tacotron2(n + 1) in a worker thread while WaveGlow(n) runs in the caller's thread."""
+    import time as _time
+    from text_to_speech_amd.tacotron2 import Tacotron2
+    from text_to_speech_amd.waveglow import WaveGlow
+
+    class SlowSynth(FakeSynth):
+        def __call__(self, inputs, **kw):
+            _time.sleep(0.05)
+            return super().__call__(inputs, **kw)
+
+    class SlowVocoder(FakeVocoder):
+        def __call__(self, mel, **kw):
+            _time.sleep(0.05)
+            return super().__call__(mel, **kw)
+
+    texts = [f'This is sentence number {i} of the stream.' for i in range(8)]
+    synth, voc = SlowSynth([], default=120), SlowVocoder()
+    model = Tacotron2(synth)
+    model.precompile_for_stream = lambda **kw: None                  # keep the timing clean
+    got = []
+    t0 = _time.time()
+    model.stream(iter(texts), vocoder=WaveGlow(voc), save=False, overlap=True,
+                 callbacks=[lambda text, audio, **_: got.append((text, len(audio)))])
+    dt = _time.time() - t0
+    assert [g[0] for g in got] == texts and all(n == 120 * 256 for _, n in got)
+    assert dt < 0.7                                                   # sequential would be 8 * 0.10 = 0.8 s
+    # same results as the sequential path
+    seq = Tacotron2(SlowSynth([], default=120)).predict(texts[:2], vocoder=WaveGlow(SlowVocoder()), save=False)
+    ovl = Tacotron2(SlowSynth([], default=120)).predict(texts[:2], vocoder=WaveGlow(SlowVocoder()), save=False, overlap=True)
+    assert [r['text'] for r in ovl] == texts[:2] and all(np.array_equal(a['audio'], b['audio']) for a, b in zip(seq, ovl))
+
+    class Boom(FakeSynth):
+        def __call__(self, inputs, **kw):
+            if len(self.calls) == 1:
+                raise RuntimeError('synth exploded')
+            return super().__call__(inputs, **kw)
+    with pytest.raises(RuntimeError, match='synth exploded'):
+        Tacotron2(Boom([], default=120)).predict(texts[:3], vocoder=WaveGlow(FakeVocoder()), save=False, overlap=True)
+
+
 def test_callbacks_failures_are_logged_not_raised(caplog):
     from text_to_speech_amd.callbacks import FunctionCallback, QueueCallback, apply_callbacks
     q = queue.Queue()
