@@ -33,11 +33,12 @@ constexpr int NB = 8;                 // batch rows processed together by the LS
 constexpr int PRE = 256, ARNN = 1024, DRNN = 1024, ATT = 128, NMEL = 80, LOCK = 31;
 constexpr int CHUNK = 32;             // decoder steps per hipGraph replay
 
-struct DecState {                     // device-resident loop state (one per call)
+struct __attribute__((aligned(32))) DecState {   // device-resident loop state (one per call); one 32-byte scalar load
     int t0;                           // first step of the current chunk
     int n_finished;                   // rows whose stop token has fired
     int steps_run;                    // loop iterations executed so far
     int B, max_len, early_stop;
+    int pad[2];
 };
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -129,10 +130,12 @@ __global__ void enc_len_kernel(const uint8_t* __restrict__ mask, int* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ decoder kernels
+// Branch-free on purpose: with short-circuit evaluation every field became its own dependent scalar load + wait + branch
+// (4-5 sequential ~0.3 us round trips at the head or tail of every step kernel); this way all fields arrive with one load.
 __device__ __forceinline__ bool step_done(const DecState* st, int j, int& t) {
-    t = st->t0 + j;
-    if (t >= st->max_len) return true;
-    return st->early_stop && st->n_finished >= st->B;
+    const int t0 = st->t0, nf = st->n_finished, nb = st->B, ml = st->max_len, es = st->early_stop;
+    t = t0 + j;
+    return (t >= ml) | ((es != 0) & (nf >= nb));
 }
 
 // prenet: grid (B, 8).  Every block recomputes layer 1 (80 -> 256) for its row, then its 32 outputs of layer 2.
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
     extern __shared__ __attribute__((aligned(16))) float xs[];      // [NBT][K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = blockIdx.x * 4 + wave;
-    // weights -> registers (issued first: the longest-latency stream)
+    // weights -> registers (the longest-latency stream)
     f32x4 w[4][KS];
     const float* wrow = Wp + (long long)(4 * u) * K + lane * 4;
 #pragma unroll
@@ -238,6 +241,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
     };
     constexpr int b0 = 0;                       // B <= NBT per launch (the host loops over batch chunks)
     issue_stage(0);
+    // Everything the epilogue needs that does not depend on this step's arithmetic (loop state, bias, old cell state) is
+    // requested here, right behind the weight and x streams, so that the tail of the kernel is arithmetic + one store
+    // instead of a second dependent memory round trip.
+    int t;
+    const bool done = step_done(st, j, t);
+    constexpr int LOGV0 = NBT == 1 ? 2 : NBT == 2 ? 3 : NBT == 4 ? 4 : 5;
+    constexpr int SH0 = 6 - LOGV0;
+    const bool writer = lane < (NBT << SH0) && (lane & ((1 << SH0) - 1)) == 0 && (lane >> SH0) < B;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(bp + 4 * u);
+    const float c_old = writer ? c_state[(long long)(lane >> SH0) * U + u] : 0.f;
     // pin the weights: without this the compiler sinks each weight load next to its first use inside the FMA loop
     // (serialising HBM round trips) when register pressure is high (NBT = 8)
 #pragma unroll
@@ -323,19 +336,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
         const float gf = __shfl(v, (1 * NBT + src_b) << SH, 64);
         const float gg = __shfl(v, (2 * NBT + src_b) << SH, 64);
         const float go = __shfl(v, (3 * NBT + src_b) << SH, 64);
-        int t;
-        const bool done = step_done(st, j, t);      // only the final stores depend on the loop state
-        if (!done && lane < (NBT << SH) && (lane & ((1 << SH) - 1)) == 0) {
+        static_assert(SH == SH0, "writer lanes");
+        if (!done && writer) {                      // only the final stores depend on the loop state
             const int b = b0 + (lane >> SH);
-            if (b < B) {
-                const float ig = sigmoid_exact(gi + bp[4 * u + 0]);
-                const float fg = sigmoid_exact(gf + bp[4 * u + 1]);
-                const float cg = tanhf(gg + bp[4 * u + 2]);
-                const float og = sigmoid_exact(go + bp[4 * u + 3]);
-                const float cn = fg * c_state[(long long)b * U + u] + ig * cg;
-                c_state[(long long)b * U + u] = cn;
-                h_new[(long long)b * U + u] = og * tanhf(cn);
-            }
+            const float ig = sigmoid_exact(gi + bias4[0]);
+            const float fg = sigmoid_exact(gf + bias4[1]);
+            const float cg = tanhf(gg + bias4[2]);
+            const float og = sigmoid_exact(go + bias4[3]);
+            const float cn = fg * c_old + ig * cg;
+            c_state[(long long)b * U + u] = cn;
+            h_new[(long long)b * U + u] = og * tanhf(cn);
         }
     }
 }
@@ -349,6 +359,8 @@ __global__ __launch_bounds__(256) void query_kernel(const DecState* __restrict__
     const int a0 = blockIdx.x * 2;
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(wq_a + (long long)a0 * ARNN + tid * 4);        // wq_a is [128][1024]
     const f32x4 w1 = *reinterpret_cast<const f32x4*>(wq_a + (long long)(a0 + 1) * ARNN + tid * 4);
+    int t;
+    const bool done = step_done(st, j, t);        // requested up front, consulted before the store
     for (int b0 = 0; b0 < B; b0 += NB) {
         f32x4 hv[NB];
 #pragma unroll
@@ -382,8 +394,7 @@ __global__ __launch_bounds__(256) void query_kernel(const DecState* __restrict__
         v += __shfl_xor(v, 1, 64);
         if ((lane & 3) == 0) red_s[(lane >> 2) >> 3][wave][(lane >> 2) & 7] = v;     // idx = lane >> 2 = a_local * NB + bb
         __syncthreads();
-        int t;
-        if (tid < 2 * NB && !step_done(st, j, t)) {
+        if (tid < 2 * NB && !done) {
             const int al = tid >> 3, bb = tid & 7;
             if (b0 + bb < B)
                 q[(long long)(b0 + bb) * ATT + a0 + al] = (red_s[al][0][bb] + red_s[al][1][bb]) + (red_s[al][2][bb] + red_s[al][3][bb]);
@@ -404,6 +415,8 @@ __global__ __launch_bounds__(256) void energies_kernel(const DecState* __restric
     __shared__ __attribute__((aligned(16))) float wl_s[2 * LOCK * ATT];
     const int b = blockIdx.x, tc = blockIdx.y, tid = threadIdx.x;
     const int tbase = tc * 16;
+    int t;
+    const bool done = step_done(st, j, t);        // requested up front, consulted before the store
     {
         constexpr int N4 = 2 * LOCK * ATT / 4;                     // 1984 float4
         f32x4 tmp[(N4 + 255) / 256];
@@ -470,8 +483,7 @@ __global__ __launch_bounds__(256) void energies_kernel(const DecState* __restric
     e += __shfl_xor(e, 2, 64);
     e += __shfl_xor(e, 4, 64);
     e += __shfl_xor(e, 8, 64);
-    int t;
-    if (al == 0 && tok && !step_done(st, j, t)) energies[(long long)b * Tin + tt] = e;
+    if (al == 0 && tok && !done) energies[(long long)b * Tin + tt] = e;
 }
 
 // softmax + context: grid (B, enc / 32).  Each block redoes the (cheap) masked softmax over Tin, then 32 context columns
@@ -494,6 +506,19 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
     __shared__ float red_s[8];
     __shared__ int redi_s[4];
     const int b = blockIdx.x, ec = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int max_len = st->max_len;
+    // The context operand (this thread's 32-column slice of `memory`, rows ts, ts + 8, ...) does not depend on the softmax:
+    // request it now so that it arrives while the softmax runs (Tin <= 8 * MPF; longer inputs take the loop below).
+    constexpr int MPF = 32;
+    const int col = tid & 31, ts = tid >> 5;
+    const float* mem = memory + (long long)b * Tin * enc + ec * 32 + col;
+    float mv[MPF];
+#pragma unroll
+    for (int i = 0; i < MPF; ++i) {
+        const int tt = ts + 8 * i;
+        mv[i] = tt < Tin ? mem[(long long)tt * enc] : 0.f;
+    }
+    const float wc_old = (ec == 0 && tid < Tin) ? w_cum[(long long)b * Tin + tid] : 0.f;     // first strided element
     // attention window (tacotron2_arch.py:630-638)
     int lo = 0, hi = Tin;
     if (win_len > 0) {
@@ -527,11 +552,13 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
     for (int tt = tid; tt < Tin; tt += 256) w_s[tt] = w_s[tt] / sum;
     __syncthreads();
     {
-        const int col = tid & 31, ts = tid >> 5;
-        const float* mem = memory + (long long)b * Tin * enc + ec * 32 + col;
         float acc = 0.f;
-#pragma unroll 16
-        for (int tt = ts; tt < Tin; tt += 8) acc = fmaf(w_s[tt], mem[(long long)tt * enc], acc);
+#pragma unroll
+        for (int i = 0; i < MPF; ++i) {
+            const int tt = ts + 8 * i;
+            if (tt < Tin) acc = fmaf(w_s[tt], mv[i], acc);
+        }
+        for (int tt = ts + 8 * MPF; tt < Tin; tt += 8) acc = fmaf(w_s[tt], mem[(long long)tt * enc], acc);
         part[ts][col] = acc;
     }
     __syncthreads();
@@ -547,8 +574,8 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
         for (int tt = tid; tt < Tin; tt += 256) {
             const float p = w_s[tt];
             w_prev[(long long)b * Tin + tt] = p;
-            w_cum[(long long)b * Tin + tt] += p;
-            if (attn_hist) attn_hist[((long long)b * st->max_len + t) * Tin + tt] = p;
+            w_cum[(long long)b * Tin + tt] = (tt == tid ? wc_old : w_cum[(long long)b * Tin + tt]) + p;
+            if (attn_hist) attn_hist[((long long)b * max_len + t) * Tin + tt] = p;
             if (p > best) { best = p; besti = tt; }          // strided order keeps the lowest index per thread
         }
         for (int s = 32; s >= 1; s >>= 1) {
@@ -583,7 +610,12 @@ __global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st,
 #pragma unroll
     for (int i = 0; i < KP; ++i) w[i] = *reinterpret_cast<const f32x4*>(pw + (long long)o * K + i * 256 + lane * 4);
     const float bias = pb[o];
+    int t;
+    const bool done = step_done(st, j, t);        // requested up front (with max_len), consulted before the stores
+    const int max_len = st->max_len;
     for (int b0 = 0; b0 < B; b0 += NB) {
+        const int bw = b0 + (lane >> 3);                     // batch row this lane will write
+        const int fin_old = (o == NMEL && (lane & 7) == 0 && bw < B) ? finished[bw] : 0;
         float acc[NB];
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
@@ -621,18 +653,17 @@ __global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st,
         v += __shfl_xor(v, 4, 64);
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 1, 64);
-        const int b = b0 + (lane >> 3);                      // lane l holds batch row l >> 3 of this chunk
-        int t;
-        if ((lane & 7) == 0 && b < B && !step_done(st, j, t)) {
+        const int b = bw;                                    // lane l holds batch row l >> 3 of this chunk
+        if ((lane & 7) == 0 && b < B && !done) {
             v += bias;
             if (o < NMEL) {
                 frame[b * NMEL + o] = v;
-                dec_out[((long long)b * st->max_len + t) * NMEL + o] = v;
+                dec_out[((long long)b * max_len + t) * NMEL + o] = v;
             } else {
                 const float sp = sigmoid_exact(v);
-                stop_out[(long long)b * st->max_len + t] = sp;
+                stop_out[(long long)b * max_len + t] = sp;
                 // finished |= stop > 0.5 ; lengths += !finished      (tacotron2_arch.py:664-665)
-                int fin = finished[b];
+                int fin = fin_old;
                 if (!fin && sp > 0.5f) {
                     fin = 1;
                     finished[b] = 1;
