@@ -515,8 +515,8 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
     float mv[MPF];
 #pragma unroll
     for (int i = 0; i < MPF; ++i) {
-        const int tt = ts + 8 * i;
-        mv[i] = tt < Tin ? mem[(long long)tt * enc] : 0.f;
+        const int tt = min(ts + 8 * i, Tin - 1);              // clamped, not predicated: 32 independent loads, no branches
+        mv[i] = mem[(long long)tt * enc];
     }
     const float wc_old = (ec == 0 && tid < Tin) ? w_cum[(long long)b * Tin + tid] : 0.f;     // first strided element
     // attention window (tacotron2_arch.py:630-638)
@@ -556,7 +556,8 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
 #pragma unroll
         for (int i = 0; i < MPF; ++i) {
             const int tt = ts + 8 * i;
-            if (tt < Tin) acc = fmaf(w_s[tt], mv[i], acc);
+            const float wv = w_s[min(tt, Tin - 1)];
+            acc = fmaf(tt < Tin ? wv : 0.f, mv[i], acc);
         }
         for (int tt = ts + 8 * MPF; tt < Tin; tt += 8) acc = fmaf(w_s[tt], mem[(long long)tt * enc], acc);
         part[ts][col] = acc;
