@@ -126,15 +126,22 @@ def secondary_metrics(eng, dev, rank):
         dt = (time.perf_counter() - t0) / reps
         out[f'tacotron2_batch{B}_mel_frames_per_s'] = B * FRAMES / dt
         out[f'tacotron2_batch{B}_us_per_decoder_step'] = 1e6 * dt / FRAMES
+        eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False, precision='f16')
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.tacotron2_infer(tok_d, max_len=FRAMES, early_stopping=False, want_attention=False, precision='f16')
+        dt = (time.perf_counter() - t0) / reps
+        out[f'tacotron2_batch{B}_f16w_mel_frames_per_s'] = B * FRAMES / dt
     # BASELINE.json configs[2] shape: full text -> audio pipeline, batch 8, mixed token counts 50..200 padded to 256,
-    # mel kept on the GPU between the two models, vocoder in the fp16-operand mode (Tacotron2 itself runs fp32).
+    # mel kept on the GPU between the two models, fp16 modes of both models (decoder LSTM weights fp16; WaveGlow GEMM
+    # operands fp16; fp32 accumulation everywhere).
     # Synthetic weights never fire the stop token, so every row decodes max_len = 800 frames (fixed-length timing run).
     from text_to_speech_amd.pipeline import TTSPipeline
     lens = [50, 70, 90, 110, 130, 150, 170, 200]
     tok = np.zeros((8, 256), np.int32)
     for i, n in enumerate(lens):
         tok[i, :n] = np.random.default_rng(6 + i).integers(1, 148, n)
-    pipe = TTSPipeline(eng, seed=0, vocoder_precision='f16')
+    pipe = TTSPipeline(eng, seed=0, vocoder_precision='f16', synthesizer_precision='f16')
     pipe.synthesize_tokens(tok, max_length=64, deterministic=True, early_stopping=False)
     t0 = time.perf_counter()
     audio, n_frames, _ = pipe.synthesize_tokens(tok, max_length=FRAMES, deterministic=True, early_stopping=False)

@@ -87,6 +87,14 @@ int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens, int B, int
                             float* mel, float* decoder_output, float* stop_tokens, float* attention,
                             int32_t* lengths, int32_t* steps_run, int mem);
 
+/* Same contract with the two decoder LSTM weight matrices (98 % of the bytes a decoder step streams) held in fp16
+ * (BASELINE configs 3 and 5: "fp16 weights, fp32 accumulate"); inputs, recurrent state, accumulation, attention, prenet,
+ * projections, encoder and postnet stay float32.  The fp16 copies are derived from the finalized weights on first use. */
+int tts_hip_tacotron2_infer_f16(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                                int max_len, int early_stop, const float* prenet_masks, int win_len, int win_offset,
+                                float* mel, float* decoder_output, float* stop_tokens, float* attention,
+                                int32_t* lengths, int32_t* steps_run, int mem);
+
 /* ---- TacotronSTFT.mel_spectrogram  (utils/audio/stft.py:242-274,306-314)
  * audio [B, N] (N >= 1024) -> mel [B, N/256 + 1, 80]                                                                */
 int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem);

@@ -81,6 +81,7 @@ struct ConvBnDev {              // conv k5 with batch-norm folded in
 struct LstmDev {                // weights packed gate-interleaved: row r = 4*u + gate
     float* W = nullptr;         // [4u][kin_total]  (input kernel rows then recurrent rows, K contiguous)
     float* b = nullptr;         // [4u]
+    _Float16* W16 = nullptr;    // fp16 copy of W for tts_hip_tacotron2_infer_f16 (built on first use)
     int units = 0, kin = 0;
 };
 struct Tacotron2Dev {

@@ -16,6 +16,8 @@
 // every kernel returns immediately once all rows are finished (device flag), which keeps the reference's
 // "stop as soon as every row has fired" semantics (:625-627) without a host round trip per step.
 #include "engine.h"
+
+#include <type_traits>
 #include "gemm_f32.h"
 
 #include <algorithm>
@@ -198,9 +200,11 @@ __global__ __launch_bounds__(256) void prenet_kernel(const DecState* __restrict_
 // keeps its 4 gate rows (i, f, c, o of one unit) in registers (KS float4 per row per lane), x for NBT batch rows is
 // staged in LDS (all loads of the staging pass in flight at once), and the 4 x NBT partial sums are reduced with a
 // lane-halving exchange (V - 1 + log2(64 / V) shuffles for V = 4 * NBT values instead of 6 V).
-template <int KS, int NBT>
+// HW: the weight rows are fp16 in memory (half the bytes of the stream that bounds this kernel); they are widened to fp32
+// once per register and everything else -- x, accumulation, gates, cell state -- stays fp32.
+template <int KS, int NBT, bool HW>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restrict__ st, int j,
-                                                        const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                        const void* __restrict__ Wp_v, const float* __restrict__ bp,
                                                         const float* __restrict__ s0, int n0,
                                                         const float* __restrict__ s1, int n1,
                                                         const float* __restrict__ h_old, float* __restrict__ h_new,
@@ -213,12 +217,15 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = blockIdx.x * 4 + wave;
     // weights -> registers (the longest-latency stream)
-    f32x4 w[4][KS];
-    const float* wrow = Wp + (long long)(4 * u) * K + lane * 4;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    typedef typename std::conditional<HW, f16x4, f32x4>::type wvec_t;
+    typedef typename std::conditional<HW, _Float16, float>::type wel_t;
+    wvec_t wraw[4][KS];
+    const wel_t* wrow = (const wel_t*)Wp_v + (long long)(4 * u) * K + lane * 4;
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-        for (int i = 0; i < KS; ++i) w[gt][i] = *reinterpret_cast<const f32x4*>(wrow + (long long)gt * K + i * 256);
+        for (int i = 0; i < KS; ++i) wraw[gt][i] = *reinterpret_cast<const wvec_t*>(wrow + (long long)gt * K + i * 256);
 
     // stage x[b][:] = [s0[b] | s1[b] | h_old[b]] for NBT rows (zeros beyond B): every load of a pass is issued before
     // any LDS store, and the first pass is issued right behind the weight loads so both streams are in flight together
@@ -256,7 +263,15 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-        for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(w[gt][i]));
+        for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(wraw[gt][i]));
+    f32x4 w[4][KS];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            if constexpr (HW) w[gt][i] = f32x4{(float)wraw[gt][i][0], (float)wraw[gt][i][1], (float)wraw[gt][i][2], (float)wraw[gt][i][3]};
+            else w[gt][i] = wraw[gt][i];
+        }
 
     {
 #pragma unroll
@@ -780,23 +795,24 @@ int conv_gemm(tts_hip_engine* e, const ConvBnDev& cv, const float* x, int ldx, f
     return TTS_HIP_OK;
 }
 
-template <int KS, int NBT>
+template <int KS, int NBT, bool HW>
 hipError_t launch_lstm(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
                        const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
     const size_t lds = (size_t)NBT * 256 * KS * sizeof(float);
-    auto kern = lstm_step_kernel<KS, NBT>;
+    auto kern = lstm_step_kernel<KS, NBT, HW>;
     static bool attr = false;
     if (!attr) {
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (er != hipSuccess) return er;
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(L.units / 4), dim3(256), lds, s, st, j, L.W, L.b, s0, n0, s1, n1, h_old, h_new,
+    const void* W = HW ? (const void*)L.W16 : (const void*)L.W;
+    hipLaunchKernelGGL(kern, dim3(L.units / 4), dim3(256), lds, s, st, j, W, L.b, s0, n0, s1, n1, h_old, h_new,
                        c_state, B, L.units);
     return hipGetLastError();
 }
 
-template <int KS>
+template <int KS, bool HW>
 hipError_t lstm_by_batch(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
                          const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
     // one launch per chunk of <= 8 batch rows (B > 8 re-streams the weights from L2 / Infinity Cache per chunk)
@@ -808,24 +824,36 @@ hipError_t lstm_by_batch(hipStream_t s, const DecState* st, int j, const LstmDev
         float* hn = h_new + (size_t)b0 * L.units;
         float* cs = c_state + (size_t)b0 * L.units;
         hipError_t er;
-        if (nb == 1) er = launch_lstm<KS, 1>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
-        else if (nb == 2) er = launch_lstm<KS, 2>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
-        else if (nb <= 4) er = launch_lstm<KS, 4>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
-        else er = launch_lstm<KS, 8>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        if (nb == 1) er = launch_lstm<KS, 1, HW>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        else if (nb == 2) er = launch_lstm<KS, 2, HW>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        else if (nb <= 4) er = launch_lstm<KS, 4, HW>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
+        else er = launch_lstm<KS, 8, HW>(s, st, j, L, a0, n0, a1, n1, ho, hn, cs, nb);
         if (er != hipSuccess) return er;
     }
     return hipSuccess;
 }
 
-hipError_t lstm_dispatch(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
-                         const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
+template <bool HW>
+hipError_t lstm_dispatch_p(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
+                           const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
     switch ((n0 + n1 + L.units) / 256) {
-        case 7: return lstm_by_batch<7>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
-        case 8: return lstm_by_batch<8>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
-        case 10: return lstm_by_batch<10>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
-        case 11: return lstm_by_batch<11>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 7: return lstm_by_batch<7, HW>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 8: return lstm_by_batch<8, HW>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 10: return lstm_by_batch<10, HW>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+        case 11: return lstm_by_batch<11, HW>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t lstm_dispatch(hipStream_t s, const DecState* st, int j, const LstmDev& L, const float* s0, int n0,
+                         const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B, bool half_w) {
+    return half_w ? lstm_dispatch_p<true>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B)
+                  : lstm_dispatch_p<false>(s, st, j, L, s0, n0, s1, n1, h_old, h_new, c_state, B);
+}
+
+__global__ void cvt_w16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (_Float16)src[i];
 }
 
 }  // namespace
@@ -833,6 +861,8 @@ hipError_t lstm_dispatch(hipStream_t s, const DecState* st, int j, const LstmDev
 void tacotron2_free(tts_hip_engine* e) {
     for (void* p : e->taco.allocs) (void)hipFree(p);
     e->taco.allocs.clear();
+    e->taco.att.W16 = nullptr;
+    e->taco.dec.W16 = nullptr;
     e->taco.ws.release();
     e->taco.io.release();
     e->taco.ready = false;
@@ -969,13 +999,57 @@ int tacotron2_finalize(tts_hip_engine* e) {
     return TTS_HIP_OK;
 }
 
+static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                                int max_len, int early_stop, const float* prenet_masks, int win_len,
+                                int win_offset, float* mel, float* decoder_output, float* stop_tokens,
+                                float* attention, int32_t* lengths, int32_t* steps_run, int mem, bool half_w);
+
 extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
                                        int max_len, int early_stop, const float* prenet_masks, int win_len,
                                        int win_offset, float* mel, float* decoder_output, float* stop_tokens,
                                        float* attention, int32_t* lengths, int32_t* steps_run, int mem) {
+    return tacotron2_infer_impl(e, tokens, B, Tin, speaker, max_len, early_stop, prenet_masks, win_len, win_offset, mel,
+                                decoder_output, stop_tokens, attention, lengths, steps_run, mem, false);
+}
+
+extern "C" int tts_hip_tacotron2_infer_f16(tts_hip_engine* e, const int32_t* tokens, int B, int Tin,
+                                           const float* speaker, int max_len, int early_stop,
+                                           const float* prenet_masks, int win_len, int win_offset, float* mel,
+                                           float* decoder_output, float* stop_tokens, float* attention,
+                                           int32_t* lengths, int32_t* steps_run, int mem) {
+    return tacotron2_infer_impl(e, tokens, B, Tin, speaker, max_len, early_stop, prenet_masks, win_len, win_offset, mel,
+                                decoder_output, stop_tokens, attention, lengths, steps_run, mem, true);
+}
+
+// fp16 copies of the two decoder LSTM weight matrices (98 % of the bytes a decoder step streams), built on first use
+static int tacotron2_build_f16(tts_hip_engine* e) {
+    Tacotron2Dev& tc = e->taco;
+    for (LstmDev* L : {&tc.att, &tc.dec}) {
+        if (L->W16) continue;
+        const long long n = 4ll * L->units * (L->kin + L->units);
+        void* p = nullptr;
+        HIPCHK(e, hipMalloc(&p, (size_t)n * sizeof(_Float16)));
+        tc.allocs.push_back(p);
+        hipLaunchKernelGGL(cvt_w16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, L->W,
+                           (_Float16*)p, n);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        L->W16 = (_Float16*)p;
+    }
+    return TTS_HIP_OK;
+}
+
+static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                                int max_len, int early_stop, const float* prenet_masks, int win_len,
+                                int win_offset, float* mel, float* decoder_output, float* stop_tokens,
+                                float* attention, int32_t* lengths, int32_t* steps_run, int mem, bool half_w) {
     if (!e) return TTS_HIP_EINVAL;
     Tacotron2Dev& tc = e->taco;
     if (!tc.ready) return set_err(e, TTS_HIP_ENOTREADY, "tacotron2 weights not finalized");
+    if (half_w) {
+        int rc16 = tacotron2_build_f16(e);
+        if (rc16) return rc16;
+    }
     if (!tokens || B <= 0 || Tin <= 0 || max_len <= 0 || Tin > 4096 || B > 1024)
         return set_err(e, TTS_HIP_EINVAL, "tacotron2_infer: bad argument");
     if (tc.spk_dim > 0 && !speaker) return set_err(e, TTS_HIP_EINVAL, "tacotron2_infer: this model needs a speaker embedding");
@@ -1121,7 +1195,7 @@ extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens,
         hipLaunchKernelGGL(prenet_kernel, dim3(B, 8), dim3(256), 0, st, d_state, j, d_frame, tc.prenet_w0,
                            tc.prenet_w1, masks_dev, d_p2);
         HIPCHK(e, hipGetLastError());
-        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.att, d_p2, PRE, d_ctx, enc, hatt_old, hatt_new, d_catt, B));
+        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.att, d_p2, PRE, d_ctx, enc, hatt_old, hatt_new, d_catt, B, half_w));
         hipLaunchKernelGGL(query_kernel, dim3(ATT / 2), dim3(256), 0, st, d_state, j, hatt_new, tc.query_w, d_q, B);
         HIPCHK(e, hipGetLastError());
         hipLaunchKernelGGL(energies_kernel, dim3(B, (Tin + 15) / 16), dim3(256), 0, st, d_state, j, d_q, tc.loc_dense,
@@ -1131,7 +1205,7 @@ extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens,
                            d_enc_len, win_len, win_offset, d_mainatt + par * B, d_mainatt + (par ^ 1) * B, d_memory,
                            d_wprev, d_wcum, d_ctx, d_attn, Tin, enc);
         HIPCHK(e, hipGetLastError());
-        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.dec, hatt_new, ARNN, d_ctx, enc, hdec_old, hdec_new, d_cdec, B));
+        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.dec, hatt_new, ARNN, d_ctx, enc, hdec_old, hdec_new, d_cdec, B, half_w));
         if (enc == 512)
             hipLaunchKernelGGL(project_kernel<6>, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
                                tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B);

@@ -119,8 +119,13 @@ class HipEngine:
 
     # ------------------------------------------------------------------ Tacotron2
     def tacotron2_infer(self, tokens, speaker=None, max_len: int = 1000, early_stopping: bool = True,
-                        prenet_masks=None, attn_mask_win_len=None, attn_mask_offset: int = 0, want_attention=True):
-        """tokens int32 [B, Tin] -> Tacotron2InferenceOutput of numpy arrays (or torch tensors for CUDA tokens)."""
+                        prenet_masks=None, attn_mask_win_len=None, attn_mask_offset: int = 0, want_attention=True,
+                        precision: str = 'f32'):
+        """tokens int32 [B, Tin] -> Tacotron2InferenceOutput of numpy arrays (or torch tensors for CUDA tokens).
+        precision 'f16': decoder LSTM weights in fp16 (fp32 accumulate and state)."""
+        if precision not in ('f32', 'f16'):
+            raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
+        fn = self._lib.tts_hip_tacotron2_infer if precision == 'f32' else self._lib.tts_hip_tacotron2_infer_f16
         dev = _is_torch_cuda(tokens)
         if dev:
             torch = self._torch()
@@ -160,7 +165,7 @@ class HipEngine:
         if dev:
             self._sync_torch()
         win = int(attn_mask_win_len) if attn_mask_win_len is not None else 0
-        self._check(self._lib.tts_hip_tacotron2_infer(
+        self._check(fn(
             self._h, ptr(tok), B, Tin, ptr(speaker), max_len, 1 if early_stopping else 0, ptr(prenet_masks),
             win, int(attn_mask_offset), ptr(mel), ptr(dec), ptr(stop), ptr(attn), ptr(lengths),
             ctypes.cast(ctypes.byref(steps), ctypes.c_void_p), MEM_DEVICE if dev else MEM_HOST), 'tacotron2_infer')

@@ -14,9 +14,10 @@ PAD_MEL_VALUE = -11.0
 
 
 class TTSPipeline:
-    def __init__(self, engine, seed=None, vocoder_precision='f32'):
+    def __init__(self, engine, seed=None, vocoder_precision='f32', synthesizer_precision='f32'):
         self.engine = engine
         self.vocoder_precision = vocoder_precision      # 'f16': BASELINE.json configs 3 / 5
+        self.synthesizer_precision = synthesizer_precision
         self._rng = np.random.default_rng(seed)
 
     def synthesize_tokens(self, tokens, speaker=None, max_length=10.0, deterministic=False, prenet_masks=None, z=None,
@@ -37,7 +38,8 @@ class TTSPipeline:
         if speaker is not None:
             speaker = torch.as_tensor(np.asarray(speaker), dtype=torch.float32).to(dev)
         out = eng.tacotron2_infer(tok, speaker=speaker, max_len=max_len, early_stopping=early_stopping,
-                                  prenet_masks=prenet_masks, want_attention=False)
+                                  prenet_masks=prenet_masks, want_attention=False,
+                                  precision=self.synthesizer_precision)
         lengths = out.lengths.clamp(min=0)
         steps = eng.last_steps
         T = int(lengths.max())

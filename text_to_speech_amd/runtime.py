@@ -58,6 +58,7 @@ class HipRuntime(Runtime):
     model  : 'tacotron2' | 'waveglow' | None (None: dispatch on the input dtype -- integer tokens vs float mels).
     vocoder_precision : 'f32' (exact fp32 MFMA, default) or 'f16' (fp16 GEMM operands with fp32 accumulation: the
              counterpart of the reference's `mixed_float16` policy, utils/keras/gpu.py).
+    synthesizer_precision : 'f32' (default) or 'f16' (decoder LSTM weights in fp16, everything else fp32).
     """
 
     def __init__(self, path, *, model=None, engine=None, reload=False, device=0, seed=None, **kwargs):
@@ -68,6 +69,9 @@ class HipRuntime(Runtime):
         self.vocoder_precision = kwargs.get('vocoder_precision', 'f32')
         if self.vocoder_precision not in ('f32', 'f16'):
             raise ValueError(f"vocoder_precision must be 'f32' or 'f16', got {self.vocoder_precision!r}")
+        self.synthesizer_precision = kwargs.get('synthesizer_precision', 'f32')
+        if self.synthesizer_precision not in ('f32', 'f16'):
+            raise ValueError(f"synthesizer_precision must be 'f32' or 'f16', got {self.synthesizer_precision!r}")
 
     @staticmethod
     def load_engine(path, device=0, speaker_embedding_dim=0, **kwargs):
@@ -101,7 +105,8 @@ class HipRuntime(Runtime):
 
     # ------------------------------------------------------------------ Tacotron2.infer (tacotron2_arch.py:866-925)
     def tacotron2_infer(self, inputs, *, max_length=None, early_stopping=True, attn_mask_offset=0.5,
-                        attn_mask_win_len=None, prenet_masks=None, deterministic=False, seed=None, **_ignored):
+                        attn_mask_win_len=None, prenet_masks=None, deterministic=False, seed=None, precision=None,
+                        **_ignored):
         if isinstance(inputs, (tuple, list)):
             tokens, speaker = inputs[0], (inputs[1] if len(inputs) > 1 else None)
         else:
@@ -130,7 +135,8 @@ class HipRuntime(Runtime):
                 prenet_masks = torch.from_numpy(prenet_masks).to(tokens.device)
         return self.engine.tacotron2_infer(
             tokens if dev else tok_np, speaker=speaker, max_len=max_len, early_stopping=bool(early_stopping),
-            prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0))
+            prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
+            precision=precision or self.synthesizer_precision)
 
     # ------------------------------------------------------------------ WaveGlow.infer (waveglow_arch.py:244-306)
     def waveglow_infer(self, mel, z=None, sigma=1.0, deterministic=False, seed=None, precision=None, **_ignored):
