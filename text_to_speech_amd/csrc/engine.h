@@ -92,7 +92,7 @@ struct Tacotron2Dev {
     float* bl_in_Bt[2] = {nullptr, nullptr};   // BiLSTM input kernels [1024][512]
     float* bl_in_b[2] = {nullptr, nullptr};    // [1024]
     float* bl_rec[2] = {nullptr, nullptr};     // recurrent kernels transposed [1024][256]
-    float* prenet_w0 = nullptr;         // [256][80]   (transposed: out-major)
+    float* prenet_w0 = nullptr;         // [20][256][4]  (k / 4, output, k % 4)
     float* prenet_w1 = nullptr;         // [256][256]
     LstmDev att, dec;
     float* query_w = nullptr;           // [128][1024]

@@ -153,9 +153,12 @@ __global__ __launch_bounds__(256) void prenet_kernel(const DecState* __restrict_
     const int o = part * 32 + (tid >> 3), sub = tid & 7;
     f32x4 wa[NMEL / 4], wb[8];
 #pragma unroll
-    for (int i = 0; i < NMEL / 4; ++i) wa[i] = *reinterpret_cast<const f32x4*>(w0 + tid * NMEL + i * 4);   // [256][80]
+    // both weight streams are lane-contiguous: w0 is packed [k / 4][256 outputs][4] (one 16-byte load per lane, 1 KiB per
+    // wave instruction); the 8 lanes of an output read 128 contiguous bytes of its w1 row per instruction.  (Row-major
+    // [256][80] rows made every lane of a wave hit its own cache line: 2 us of the kernel's 4.5.)
+    for (int i = 0; i < NMEL / 4; ++i) wa[i] = *reinterpret_cast<const f32x4*>(w0 + ((long long)i * PRE + tid) * 4);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) wb[i] = *reinterpret_cast<const f32x4*>(w1 + o * PRE + sub * 32 + i * 4);
+    for (int i = 0; i < 8; ++i) wb[i] = *reinterpret_cast<const f32x4*>(w1 + o * PRE + i * 32 + sub * 4);
     if (tid < NMEL) f_s[tid] = frame[b * NMEL + tid];
     int t;
     const bool done = step_done(st, j, t);
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void prenet_kernel(const DecState* __restrict_
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const f32x4 pv = *reinterpret_cast<const f32x4*>(p1_s + sub * 32 + i * 4);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(p1_s + i * 32 + sub * 4);
             acc = fmaf(pv[0], wb[i][0], acc);
             acc = fmaf(pv[1], wb[i][1], acc);
             acc = fmaf(pv[2], wb[i][2], acc);
@@ -425,20 +428,23 @@ __global__ __launch_bounds__(256) void query_kernel(const DecState* __restrict__
     }
 }
 
-// energies: grid (B, ceil(Tin / 16)).  The location conv (2 -> 32, k 31) and dense (32 -> 128) are folded at load time
-// into one [62][128] map (no nonlinearity in between); e[t] = sum_a v[a] * tanh(q[a] + pm[t][a] + loc[t][a]).
+// energies: grid (B, ceil(Tin / 4)), one wave per input position, one lane per pair of attention dims.  The location conv
+// (2 -> 32, k 31) and dense (32 -> 128) are folded at load time into one [62][128] map (no nonlinearity in between);
+// e[t] = sum_a v[a] * tanh(q[a] + pm[t][a] + loc[t][a]).  The map is staged once per block in LDS (coalesced), each lane
+// then streams its two columns with 62 ds_read_b64 while the previous / cumulative alignment window of the wave's position
+// sits in the first 31 lanes and is broadcast with readlane.  (The first version gave a thread 8 dims of one of 16
+// positions and re-read 2 x float4 of the map per tap and thread: 1.9 us of LDS traffic in a 5.4 us kernel.)
+constexpr int EPB = 4;                     // positions per block
 __global__ __launch_bounds__(256) void energies_kernel(const DecState* __restrict__ st, int j,
                                                        const float* __restrict__ q, const float* __restrict__ wloc,
                                                        const float* __restrict__ v_w, const float* __restrict__ pm,
                                                        const float* __restrict__ w_prev,
                                                        const float* __restrict__ w_cum, float* __restrict__ energies,
                                                        int Tin) {
-    __shared__ float cat_s[2][16 + LOCK - 1];
     __shared__ __attribute__((aligned(16))) float wl_s[2 * LOCK * ATT];
-    const int b = blockIdx.x, tc = blockIdx.y, tid = threadIdx.x;
-    const int tbase = tc * 16;
-    int t;
-    const bool done = step_done(st, j, t);        // requested up front, consulted before the store
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tt = blockIdx.y * EPB + wave;                        // this wave's position
+    const bool tok = tt < Tin;
     {
         constexpr int N4 = 2 * LOCK * ATT / 4;                     // 1984 float4
         f32x4 tmp[(N4 + 255) / 256];
@@ -454,63 +460,42 @@ __global__ __launch_bounds__(256) void energies_kernel(const DecState* __restric
             if (idx < N4) *reinterpret_cast<f32x4*>(wl_s + idx * 4) = tmp[i];
         }
     }
-    if (tid < 2 * (16 + LOCK - 1)) {
-        const int c = tid / (16 + LOCK - 1), p = tid % (16 + LOCK - 1);
-        const int tt = tbase + p - (LOCK / 2);
-        float v = 0.f;
-        if (tt >= 0 && tt < Tin) v = (c == 0 ? w_prev : w_cum)[(long long)b * Tin + tt];
-        cat_s[c][p] = v;
-    }
-    // thread (tl, al): position tbase + tl, attention dims al*8 .. al*8+7
-    const int tl = tid >> 4, al = tid & 15;
-    const int tt = tbase + tl;
-    const bool tok = tt < Tin;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const float* pmr = pm + ((long long)b * Tin + (tok ? tt : 0)) * ATT + al * 8;
-    const f32x4 pm0 = tok ? *reinterpret_cast<const f32x4*>(pmr) : zero4;
-    const f32x4 pm1 = tok ? *reinterpret_cast<const f32x4*>(pmr + 4) : zero4;
-    const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + (long long)b * ATT + al * 8);
-    const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + (long long)b * ATT + al * 8 + 4);
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(v_w + al * 8);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(v_w + al * 8 + 4);
+    // alignment window of this position: lane i < 31 holds w_prev / w_cum at tt + i - 15 (0 outside the sequence)
+    const int tw = tt + lane - LOCK / 2;
+    const bool win = lane < LOCK && tw >= 0 && tw < Tin;
+    const float cp = win ? w_prev[(long long)b * Tin + tw] : 0.f;
+    const float cc = win ? w_cum[(long long)b * Tin + tw] : 0.f;
+    const f32x2 zero2 = {0.f, 0.f};
+    const f32x2 pmv = tok ? *reinterpret_cast<const f32x2*>(pm + ((long long)b * Tin + tt) * ATT + lane * 2) : zero2;
+    const f32x2 qv = *reinterpret_cast<const f32x2*>(q + (long long)b * ATT + lane * 2);
+    const f32x2 vv = *reinterpret_cast<const f32x2*>(v_w + lane * 2);
+    int t;
+    const bool done = step_done(st, j, t);        // requested up front, consulted before the store
     __syncthreads();
-    float loc[8];
+    f32x2 loc = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) loc[i] = 0.f;
-#pragma unroll 4
-    for (int jj = 0; jj < LOCK; ++jj)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float cv = cat_s[c][tl + jj];
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl_s + (jj * 2 + c) * ATT + al * 8);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl_s + (jj * 2 + c) * ATT + al * 8 + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                loc[i] = fmaf(cv, w0[i], loc[i]);
-                loc[4 + i] = fmaf(cv, w1[i], loc[4 + i]);
-            }
-        }
-    float e = 0.f;
-    if (tok) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            e = fmaf(v0[i], tanhf(q0[i] + pm0[i] + loc[i]), e);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            e = fmaf(v1[i], tanhf(q1[i] + pm1[i] + loc[4 + i]), e);
-        }
+    for (int jj = 0; jj < LOCK; ++jj) {
+        const float sp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cp), jj));
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cc), jj));
+        const f32x2 w0 = *reinterpret_cast<const f32x2*>(wl_s + (jj * 2 + 0) * ATT + lane * 2);
+        const f32x2 w1 = *reinterpret_cast<const f32x2*>(wl_s + (jj * 2 + 1) * ATT + lane * 2);
+        loc[0] = fmaf(sp, w0[0], loc[0]);
+        loc[1] = fmaf(sp, w0[1], loc[1]);
+        loc[0] = fmaf(sc, w1[0], loc[0]);
+        loc[1] = fmaf(sc, w1[1], loc[1]);
     }
-    e += __shfl_xor(e, 1, 64);
-    e += __shfl_xor(e, 2, 64);
-    e += __shfl_xor(e, 4, 64);
-    e += __shfl_xor(e, 8, 64);
-    if (al == 0 && tok && !done) energies[(long long)b * Tin + tt] = e;
+    float e = vv[0] * tanhf(qv[0] + pmv[0] + loc[0]);
+    e = fmaf(vv[1], tanhf(qv[1] + pmv[1] + loc[1]), e);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) e += __shfl_xor(e, m, 64);
+    if (lane == 0 && tok && !done) energies[(long long)b * Tin + tt] = e;
 }
 
-// softmax + context: grid (B, enc / 32).  Each block redoes the (cheap) masked softmax over Tin, then 32 context columns
-// (8 interleaved slices of Tin per column, loads unrolled); block y == 0 also updates w_prev / w_cum, the alignment
-// history and main_attention (argmax, first index on ties).
+// softmax + context: grid (B, enc / 32).  Every wave gets the masked softmax statistics (max, sum) over Tin with shuffles
+// only; thread tt then writes weight tt to LDS once, and each thread accumulates 1/8 of one of the block's 32 context
+// columns from operands it requested at the top of the kernel.  Two barriers instead of the five of the first version
+// (4.8 -> 3.x us).  Block y == 0 also updates w_prev / w_cum, the alignment history and main_attention (argmax, first
+// index on ties).
 __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __restrict__ st, int j,
                                                           const float* __restrict__ energies,
                                                           const uint8_t* __restrict__ mask,
@@ -520,17 +505,13 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
                                                           float* __restrict__ w_prev, float* __restrict__ w_cum,
                                                           float* __restrict__ ctx, float* __restrict__ attn_hist,
                                                           int Tin, int enc) {
-    int t;
-    const bool done = step_done(st, j, t);        // consulted only before the stores below
-    extern __shared__ float sm[];                 // [Tin] weights
-    float* w_s = sm;
-    __shared__ float part[8][32];
-    __shared__ float red_s[8];
+    extern __shared__ float w_s[];                // [Tin] softmax weights
+    __shared__ float part[4][32];
+    __shared__ float red_s[4];
     __shared__ int redi_s[4];
     const int b = blockIdx.x, ec = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int max_len = st->max_len;
     // The context operand (this thread's 32-column slice of `memory`, rows ts, ts + 8, ...) does not depend on the softmax:
-    // request it now so that it arrives while the softmax runs (Tin <= 8 * MPF; longer inputs take the loop below).
+    // request it first so that it arrives while the statistics are computed (Tin <= 8 * MPF; longer inputs: loop below).
     constexpr int MPF = 32;
     const int col = tid & 31, ts = tid >> 5;
     const float* mem = memory + (long long)b * Tin * enc + ec * 32 + col;
@@ -540,7 +521,10 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
         const int tt = min(ts + 8 * i, Tin - 1);              // clamped, not predicated: 32 independent loads, no branches
         mv[i] = mem[(long long)tt * enc];
     }
-    const float wc_old = (ec == 0 && tid < Tin) ? w_cum[(long long)b * Tin + tid] : 0.f;     // first strided element
+    const float wc_old = (ec == 0 && tid < Tin) ? w_cum[(long long)b * Tin + tid] : 0.f;
+    int t;
+    const bool done = step_done(st, j, t);        // consulted only before the stores below
+    const int max_len = st->max_len;
     // attention window (tacotron2_arch.py:630-638)
     int lo = 0, hi = Tin;
     if (win_len > 0) {
@@ -549,29 +533,55 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
         lo = center - win_off;
         hi = center - win_off + win_len;          // inclusive upper bound
     }
-    float mx = -INFINITY;
-    for (int tt = tid; tt < Tin; tt += 256) {
-        bool on = mask[(long long)b * Tin + tt] != 0;
+    const float* eb = energies + (long long)b * Tin;
+    const uint8_t* mb = mask + (long long)b * Tin;
+    auto masked_energy = [&](int tt) -> float {          // -inf at padded tokens and outside the window
+        bool on = mb[tt] != 0;
         if (win_len > 0) on = on && tt >= lo && tt <= hi;
-        const float e = on ? energies[(long long)b * Tin + tt] : -INFINITY;
-        w_s[tt] = e;
-        mx = fmaxf(mx, e);
+        return on ? eb[tt] : -INFINITY;
+    };
+    // wave-level statistics: lane covers tt = lane + 64 k; the first four (Tin <= 256) stay in registers
+    float ev[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tt = lane + 64 * k;
+        ev[k] = tt < Tin ? masked_energy(tt) : -INFINITY;
     }
-    for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
-    if (lane == 0) red_s[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+    float mx = fmaxf(fmaxf(ev[0], ev[1]), fmaxf(ev[2], ev[3]));
+    for (int tt = lane + 256; tt < Tin; tt += 64) mx = fmaxf(mx, masked_energy(tt));
+#pragma unroll
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s2, 64));
     float sum = 0.f;
-    for (int tt = tid; tt < Tin; tt += 256) {
-        const float p = expf(w_s[tt] - mx);       // exp(-inf) = 0 at masked positions
-        w_s[tt] = p;
-        sum += p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sum += expf(ev[k] - mx);       // exp(-inf) = 0 at masked / out-of-range positions
+    for (int tt = lane + 256; tt < Tin; tt += 64) sum += expf(masked_energy(tt) - mx);
+#pragma unroll
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) sum += __shfl_xor(sum, s2, 64);
+    // weight tt = tid (wave w holds it in ev[w]); longer inputs continue in strides of 256
+    float best = -1.f;
+    int besti = 0x7fffffff;
+    {
+        const float e_own = wave == 0 ? ev[0] : wave == 1 ? ev[1] : wave == 2 ? ev[2] : ev[3];
+        for (int tt = tid; tt < Tin; tt += 256) {
+            const float p = expf((tt < 256 ? e_own : masked_energy(tt)) - mx) / sum;
+            w_s[tt] = p;
+            if (ec == 0 && !done) {
+                w_prev[(long long)b * Tin + tt] = p;
+                w_cum[(long long)b * Tin + tt] = (tt == tid ? wc_old : w_cum[(long long)b * Tin + tt]) + p;
+                if (attn_hist) attn_hist[((long long)b * max_len + t) * Tin + tt] = p;
+                if (p > best) { best = p; besti = tt; }      // strided order keeps the lowest index per thread
+            }
+        }
     }
-    for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s, 64);
-    if (lane == 0) red_s[4 + wave] = sum;
-    __syncthreads();
-    sum = (red_s[4] + red_s[5]) + (red_s[6] + red_s[7]);
-    for (int tt = tid; tt < Tin; tt += 256) w_s[tt] = w_s[tt] / sum;
+    if (ec == 0 && !done) {
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) {
+            const float ob = __shfl_xor(best, s2, 64);
+            const int oi = __shfl_xor(besti, s2, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) { red_s[wave] = best; redi_s[wave] = besti; }
+    }
     __syncthreads();
     {
         float acc = 0.f;
@@ -582,38 +592,16 @@ __global__ __launch_bounds__(256) void softmax_ctx_kernel(const DecState* __rest
             acc = fmaf(tt < Tin ? wv : 0.f, mv[i], acc);
         }
         for (int tt = ts + 8 * MPF; tt < Tin; tt += 8) acc = fmaf(w_s[tt], mem[(long long)tt * enc], acc);
-        part[ts][col] = acc;
+        acc += __shfl_xor(acc, 32, 64);                   // the wave's two time slices of this column
+        if (lane < 32) part[wave][lane] = acc;
+    }
+    if (ec == 0 && !done && tid == 0) {
+        for (int w2 = 1; w2 < 4; ++w2)
+            if (red_s[w2] > best || (red_s[w2] == best && redi_s[w2] < besti)) { best = red_s[w2]; besti = redi_s[w2]; }
+        main_att[b] = besti;
     }
     __syncthreads();
-    if (tid < 32 && !done) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v += part[k][tid];
-        ctx[(long long)b * enc + ec * 32 + tid] = v;
-    }
-    if (ec == 0 && !done) {
-        float best = -1.f;
-        int besti = 0x7fffffff;
-        for (int tt = tid; tt < Tin; tt += 256) {
-            const float p = w_s[tt];
-            w_prev[(long long)b * Tin + tt] = p;
-            w_cum[(long long)b * Tin + tt] = (tt == tid ? wc_old : w_cum[(long long)b * Tin + tt]) + p;
-            if (attn_hist) attn_hist[((long long)b * max_len + t) * Tin + tt] = p;
-            if (p > best) { best = p; besti = tt; }          // strided order keeps the lowest index per thread
-        }
-        for (int s = 32; s >= 1; s >>= 1) {
-            const float ob = __shfl_xor(best, s, 64);
-            const int oi = __shfl_xor(besti, s, 64);
-            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-        }
-        if (lane == 0) { red_s[wave] = best; redi_s[wave] = besti; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w2 = 1; w2 < 4; ++w2)
-                if (red_s[w2] > best || (red_s[w2] == best && redi_s[w2] < besti)) { best = red_s[w2]; besti = redi_s[w2]; }
-            main_att[b] = besti;
-        }
-    }
+    if (tid < 32 && !done) ctx[(long long)b * enc + ec * 32 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
 // projection + stop token + bookkeeping.  grid = 21 blocks x 4 waves = 84 waves >= 81 outputs; wave `o` computes
@@ -915,7 +903,12 @@ int tacotron2_finalize(tts_hip_engine* e) {
     }
     NEED(p0, "decoder/prenet/layer_0/kernel");
     NEED(p1, "decoder/prenet/layer_1/kernel");
-    TCHK(upload_transposed(e, p0, NMEL, PRE, NMEL, &tc.prenet_w0, al));
+    {   // layer 0: Keras [80][256] -> [k / 4][256][4]
+        std::vector<float> w0p((size_t)NMEL * PRE);
+        for (int k = 0; k < NMEL; ++k)
+            for (int o = 0; o < PRE; ++o) w0p[((size_t)(k / 4) * PRE + o) * 4 + (k & 3)] = p0->data[(size_t)k * PRE + o];
+        TCHK(upload(e, w0p.data(), w0p.size(), &tc.prenet_w0, al));
+    }
     TCHK(upload_transposed(e, p1, PRE, PRE, PRE, &tc.prenet_w1, al));
     NEED(ak, "decoder/attention_rnn/kernel");
     NEED(ar, "decoder/attention_rnn/recurrent_kernel");
@@ -1192,6 +1185,11 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
     HIPCHK(e, hipGetLastError());
     const size_t sm_lds = (size_t)Tin * sizeof(float);
+    // Measurement hook (results are garbage when set): TTS_HIP_DEBUG_ONLY_KERNEL=k launches only step kernel k (0 prenet,
+    // 1 attention LSTM, 2 query, 3 energies, 4 softmax_ctx, 5 decoder LSTM, 6 project) seven times per step, which gives
+    // that kernel's cost inside the graph without the other six around it (scripts/run_taco.py prints the step time).
+    const char* only_env = getenv("TTS_HIP_DEBUG_ONLY_KERNEL");
+    const int only = only_env ? atoi(only_env) : -1;
     auto enqueue_step = [&](int j) -> int {
         const int par = j & 1;                       // CHUNK is even, so the parity of t equals the parity of j
         float* hatt_old = d_hatt + (size_t)par * B * ARNN;
@@ -1199,27 +1197,61 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
         float* hdec_old = d_hdec + (size_t)par * B * DRNN;
         float* hdec_new = d_hdec + (size_t)(par ^ 1) * B * DRNN;
         timing_begin(e, 2);
-        hipLaunchKernelGGL(prenet_kernel, dim3(B, 8), dim3(256), 0, st, d_state, j, d_frame, tc.prenet_w0,
-                           tc.prenet_w1, masks_dev, d_p2);
-        HIPCHK(e, hipGetLastError());
-        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.att, d_p2, PRE, d_ctx, enc, hatt_old, hatt_new, d_catt, B, half_w));
-        hipLaunchKernelGGL(query_kernel, dim3(ATT / 2), dim3(256), 0, st, d_state, j, hatt_new, tc.query_w, d_q, B);
-        HIPCHK(e, hipGetLastError());
-        hipLaunchKernelGGL(energies_kernel, dim3(B, (Tin + 15) / 16), dim3(256), 0, st, d_state, j, d_q, tc.loc_dense,
-                           tc.value_w, d_pm, d_wprev, d_wcum, d_energy, Tin);
-        HIPCHK(e, hipGetLastError());
-        hipLaunchKernelGGL(softmax_ctx_kernel, dim3(B, enc / 32), dim3(256), sm_lds, st, d_state, j, d_energy, d_mask,
-                           d_enc_len, win_len, win_offset, d_mainatt + par * B, d_mainatt + (par ^ 1) * B, d_memory,
-                           d_wprev, d_wcum, d_ctx, d_attn, Tin, enc);
-        HIPCHK(e, hipGetLastError());
-        HIPCHK(e, lstm_dispatch(st, d_state, j, tc.dec, hatt_new, ARNN, d_ctx, enc, hdec_old, hdec_new, d_cdec, B, half_w));
-        if (enc == 512)
-            hipLaunchKernelGGL(project_kernel<6>, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
-                               tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B);
-        else
-            hipLaunchKernelGGL(project_kernel<7>, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
-                               tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B);
-        HIPCHK(e, hipGetLastError());
+        auto k_prenet = [&]() -> int {
+            hipLaunchKernelGGL(prenet_kernel, dim3(B, 8), dim3(256), 0, st, d_state, j, d_frame, tc.prenet_w0,
+                               tc.prenet_w1, masks_dev, d_p2);
+            HIPCHK(e, hipGetLastError());
+            return TTS_HIP_OK;
+        };
+        auto k_att = [&]() -> int {
+            HIPCHK(e, lstm_dispatch(st, d_state, j, tc.att, d_p2, PRE, d_ctx, enc, hatt_old, hatt_new, d_catt, B, half_w));
+            return TTS_HIP_OK;
+        };
+        auto k_query = [&]() -> int {
+            hipLaunchKernelGGL(query_kernel, dim3(ATT / 2), dim3(256), 0, st, d_state, j, hatt_new, tc.query_w, d_q, B);
+            HIPCHK(e, hipGetLastError());
+            return TTS_HIP_OK;
+        };
+        auto k_energies = [&]() -> int {
+            hipLaunchKernelGGL(energies_kernel, dim3(B, (Tin + EPB - 1) / EPB), dim3(256), 0, st, d_state, j, d_q, tc.loc_dense,
+                               tc.value_w, d_pm, d_wprev, d_wcum, d_energy, Tin);
+            HIPCHK(e, hipGetLastError());
+            return TTS_HIP_OK;
+        };
+        auto k_softmax = [&]() -> int {
+            hipLaunchKernelGGL(softmax_ctx_kernel, dim3(B, enc / 32), dim3(256), sm_lds, st, d_state, j, d_energy, d_mask,
+                               d_enc_len, win_len, win_offset, d_mainatt + par * B, d_mainatt + (par ^ 1) * B, d_memory,
+                               d_wprev, d_wcum, d_ctx, d_attn, Tin, enc);
+            HIPCHK(e, hipGetLastError());
+            return TTS_HIP_OK;
+        };
+        auto k_dec = [&]() -> int {
+            HIPCHK(e, lstm_dispatch(st, d_state, j, tc.dec, hatt_new, ARNN, d_ctx, enc, hdec_old, hdec_new, d_cdec, B, half_w));
+            return TTS_HIP_OK;
+        };
+        auto k_project = [&]() -> int {
+            if (enc == 512)
+                hipLaunchKernelGGL(project_kernel<6>, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
+                                   tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B);
+            else
+                hipLaunchKernelGGL(project_kernel<7>, dim3(21), dim3(256), 0, st, d_state, j, hdec_new, d_ctx, tc.proj_w,
+                                   tc.proj_b, d_frame, d_decout, d_stop, d_finished, d_lengths, B);
+            HIPCHK(e, hipGetLastError());
+            return TTS_HIP_OK;
+        };
+        int rcs = TTS_HIP_OK;
+        for (int k = 0; k < 7 && rcs == TTS_HIP_OK; ++k) {
+            switch (only >= 0 ? only : k) {
+                case 0: rcs = k_prenet(); break;
+                case 1: rcs = k_att(); break;
+                case 2: rcs = k_query(); break;
+                case 3: rcs = k_energies(); break;
+                case 4: rcs = k_softmax(); break;
+                case 5: rcs = k_dec(); break;
+                default: rcs = k_project(); break;
+            }
+        }
+        if (rcs) return rcs;
         timing_end(e);
         return TTS_HIP_OK;
     };
