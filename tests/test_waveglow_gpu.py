@@ -88,6 +88,18 @@ def test_waveglow_bad_precision(gpu_engine):
 # ---- the 256-row-tile kernels (the ones the headline config runs) ---------------------------------------------------
 # B*T = 256 frames pads to the same number of rows with 128- and 256-row tiles, so waveglow_run picks the 256-row kernels
 # (fp32: 4 waves, 256 x 128 blocks; fp16: 8 waves, 256 x 256 blocks) -- the small cases above all take the 128-row ones.
+def test_waveglow_128x64_tiles_match_oracle(gpu_engine, wg_weights, wg_cfg):
+    """B*T = 100 frames: 64- and 128-row padding coincide (128 rows per phase), so the run takes the 128 x 64 tile kernels
+    (short utterances: twice the blocks); the tiny cases above take the 64-row-tile kernels, config 2 the 256-row ones."""
+    from oracle import waveglow_ref
+    mel, z = _inputs(1, 100, seed=51)
+    ref = waveglow_ref.infer(mel, wg_weights, wg_cfg, z=z, sigma=1.0)
+    err = rms(gpu_engine.waveglow_infer(mel, z=z, sigma=1.0) - ref)
+    err16 = rms(gpu_engine.waveglow_infer(mel, z=z, sigma=1.0, precision='f16') - ref)
+    print(f'128x64 tiles: f32 rms_err={err:.3e}  f16 rms_err={err16:.3e}')
+    assert err <= RMS_TOL and err16 <= F16_RMS_TOL
+
+
 def test_waveglow_256_row_tiles_match_oracle(gpu_engine, wg_weights, wg_cfg):
     from oracle import waveglow_ref
     mel, z = _inputs(2, 128, seed=31)

@@ -587,6 +587,14 @@ inline hipError_t gemm_wn_res_64(const GemmArgs& g, hipStream_t s) { return laun
 inline hipError_t gemm_wn_in_64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
 inline hipError_t gemm_wn_in0_64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
 inline hipError_t gemm_wn_res_64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 2, TTS_WN_BK, 4, TAG_WN_RES_SKIP, 0, PIPE_DMA, true>(g, 1, s); }
+// 64 x 128 tiles (2 x 2 waves): phase blocks are padded to the M tile, so short utterances waste up to BM - 1 frames per
+// phase; 64-row tiles halve that padding (e.g. 170 frames: 192 rows per phase instead of 256)
+inline hipError_t gemm_wn_in_r64(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_IN, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_in0_r64(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_IN0, WN_TAPS, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_res_r64(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
+inline hipError_t gemm_wn_in_r64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
+inline hipError_t gemm_wn_in0_r64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
+inline hipError_t gemm_wn_res_r64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_RES_SKIP, 0, PIPE_DMA, true>(g, 1, s); }
 // fp16-operand variants (activations and weights fp16 in HBM, fp32 accumulate): same tiles and pipeline
 #ifndef TTS_H_NBUF
 #define TTS_H_NBUF 3   // LDS buffers of that kernel (4 = three tiles in flight was measured no faster: 898 vs 855-885 us)

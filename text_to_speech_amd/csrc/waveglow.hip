@@ -600,12 +600,16 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     }
     const int BT = B * T;                                        // frames
     // rows per phase block, padded to the M tile: 256-row tiles unless 128-row tiles save at least 5 % of the rows
-    const int pr256 = (BT + 255) / 256 * 256, pr128 = (BT + 127) / 128 * 128;
+    const int pr256 = (BT + 255) / 256 * 256, pr128 = (BT + 127) / 128 * 128, pr64 = (BT + 63) / 64 * 64;
     const bool tile128 = pr128 * 1.05 < pr256;
-    const int PR = tile128 ? pr128 : pr256;
+    // short utterances (a sentence at batch 1): 64-row tiles when they save padding
+    const int pr_big = tile128 ? pr128 : pr256;
+    const bool row64 = BT <= 512 && getenv("TTS_HIP_NO_ROW64") == nullptr &&
+                       (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
+    const int PR = row64 ? pr64 : tile128 ? pr128 : pr256;
     const long long M = (long long)NPH * PR;                     // phase-major rows (incl. padding)
-    // short utterances: 128 x 128 tiles would leave block slots (3 per CU) empty -> 128 x 64 tiles, twice the blocks
-    const bool tile64 = tile128 && (M / 128) * 8 < 768;
+    // 128 x 128 tiles would leave block slots (3 per CU) empty -> 128 x 64 tiles, twice the blocks
+    const bool tile64 = !row64 && tile128 && (M / 128) * 8 < 768;
     if ((double)M * C * 4.0 >= 2147483648.0 - 65536.0)
         return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: B*T = %d frames exceeds one call's limit (~32000)", BT);
     HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
@@ -679,8 +683,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 g.out0 = acts_i;
                 g.ld0 = C;
                 timing_begin(e, i == 0 ? 3 : 0);
-                if (i == 0) HIPCHK(e, tile64 ? gemm_wn_in0_64(g, st) : tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
-                else HIPCHK(e, tile64 ? gemm_wn_in_64(g, st) : tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
+                if (i == 0) HIPCHK(e, row64 ? gemm_wn_in0_r64(g, st) : tile64 ? gemm_wn_in0_64(g, st) : tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
+                else HIPCHK(e, row64 ? gemm_wn_in_r64(g, st) : tile64 ? gemm_wn_in_64(g, st) : tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
                 timing_end(e);
                 if (i < 7) {             // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
                     GemmArgs r{};
@@ -699,7 +703,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.ld0 = C;
                     r.acc0 = 1;
                     timing_begin(e, 1);
-                    HIPCHK(e, tile64 ? gemm_wn_res_64(r, st) : gemm_wn_res_skip(r, st));
+                    HIPCHK(e, row64 ? gemm_wn_res_r64(r, st) : tile64 ? gemm_wn_res_64(r, st) : gemm_wn_res_skip(r, st));
                     timing_end(e);
                 }
             } else {
@@ -724,7 +728,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 g.out0h = acts_i;
                 g.ld0h = C;
                 timing_begin(e, i == 0 ? 3 : 0);
-                if (tile64) HIPCHK(e, i == 0 ? gemm_wn_in0_64h(g, st) : gemm_wn_in_64h(g, st));
+                if (row64) HIPCHK(e, i == 0 ? gemm_wn_in0_r64h(g, st) : gemm_wn_in_r64h(g, st));
+                else if (tile64) HIPCHK(e, i == 0 ? gemm_wn_in0_64h(g, st) : gemm_wn_in_64h(g, st));
                 else HIPCHK(e, i == 0 ? gemm_wn_in0_h(g, tile128, st) : gemm_wn_in_h(g, tile128, st));
                 timing_end(e);
                 if (i < 7) {
@@ -746,7 +751,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.out0h = x16;           // fp16 shadow = operand of the next layer's taps
                     r.ld0h = C;
                     timing_begin(e, 1);
-                    HIPCHK(e, tile64 ? gemm_wn_res_64h(r, st) : gemm_wn_res_h(r, st));
+                    HIPCHK(e, row64 ? gemm_wn_res_r64h(r, st) : tile64 ? gemm_wn_res_64h(r, st) : gemm_wn_res_h(r, st));
                     timing_end(e);
                 }
             }
