@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const DecState* __restri
             // decoder LSTM (KS >= 10): stream past the L2, so that the attention LSTM's rows -- 1.8 MB per XCD in fp16, the
             // same rows on the same XCD every step -- stay resident in the 4 MB L2 (fp16 mode: 35.1 -> 33.8 us/step;
             // fp32, 3.7 MB per XCD: neutral)
-            if constexpr (KS >= 10) wraw[gt][i] = __builtin_nontemporal_load(wp);
+            if constexpr (KS >= 10 || !HW) wraw[gt][i] = __builtin_nontemporal_load(wp);
             else wraw[gt][i] = *wp;
         }
 
