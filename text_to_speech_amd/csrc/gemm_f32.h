@@ -50,6 +50,7 @@ struct GemmArgs {
     int nseg;
     ASeg seg[MAX_SEG];
     long long strideAz;             // per-blockIdx.z offset added to every segment pointer
+    int shift_z;                    // per-blockIdx.z row shift added to every SEG_ROWS segment (conv taps as z slices)
     const float* Bt;                // [N][ldb]
     long long ldb;
     long long strideBz;
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             vshift = sg.shift;
             abs_row = (long long)f0 + sg.shift;
         } else {
-            vshift = sg.shift;
-            abs_row = (long long)m0 + sg.shift;
+            vshift = sg.shift + (int)z * g.shift_z;
+            abs_row = (long long)m0 + vshift;
         }
     };
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.Bt + z * g.strideBz + (long long)n0 * g.ldb);

@@ -822,22 +822,65 @@ int upload_transposed(tts_hip_engine* e, const HostTensor* t, int K, int N, int 
     return upload(e, tr.data(), tr.size(), dst, allocs);
 }
 
+// out[m][n] = act(mask(sum_z part[z][m][n] + bias[n]))  -- second half of a conv computed as one K slice per tap
+__global__ void conv_reduce_kernel(const float* __restrict__ part, long long zstride, int nz,
+                                   const float* __restrict__ bias, const float* __restrict__ altbias,
+                                   const uint8_t* __restrict__ rowmask, int mask_out, int act, float* __restrict__ out,
+                                   int N, long long total4) {
+    const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= total4) return;
+    const long long idx = i4 * 4;
+    const long long m = idx / N;
+    const int n = (int)(idx % N);
+    f32x4 v = *reinterpret_cast<const f32x4*>(bias + n);
+    for (int zz = 0; zz < nz; ++zz) v += *reinterpret_cast<const f32x4*>(part + zz * zstride + idx);
+    if (rowmask && rowmask[m] == 0) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        v = mask_out ? zero : *reinterpret_cast<const f32x4*>(altbias + n);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = act == ACT_RELU ? fmaxf(v[k], 0.f) : act == ACT_TANH ? tanhf(v[k]) : v[k];
+    *reinterpret_cast<f32x4*>(out + idx) = v;
+}
+
+// k = 5 "same" conv + folded batch-norm (+ activation, + masking) as an implicit GEMM over the 5 taps.  Few output tiles
+// (an utterance's encoder or postnet: M = 100..800 rows) leave most CUs idle and make the K = 5 * 512 MFMA chain of one
+// 32 x 32 tile the critical path (1280 x 64 cycles = 34 us), so small problems run one K slice per tap (blockIdx.z = tap:
+// 5x the blocks, 1/5 of the chain) into `scratch` [5][M][cout] and a vectorised pass adds the slices, bias, mask and
+// activation.  Large ones (>= 512 tiles) keep the single-pass kernel with the fused epilogue.
 int conv_gemm(tts_hip_engine* e, const ConvBnDev& cv, const float* x, int ldx, float* out, int M, int L,
-              const uint8_t* rowmask, int act, int mask_out) {
+              const uint8_t* rowmask, int act, int mask_out, float* scratch, size_t scratch_floats) {
     GemmArgs g{};
     g.M = M;
     g.N = cv.cout;
     g.L = L;
-    g.nseg = 5;
-    for (int tap = 0; tap < 5; ++tap) g.seg[tap] = ASeg{x, ldx, tap - 2, cv.cin, cv.cin_pad};
     g.Bt = cv.Bt;
     g.ldb = 5ll * cv.cin_pad;
-    g.bias = cv.bias;
     g.mode = EPI_LINEAR;
-    g.act = act;
     g.split = cv.cout;
-    g.out0 = out;
     g.ld0 = cv.cout;
+    const long long tiles = (long long)((M + 63) / 64) * ((cv.cout + 63) / 64);
+    const size_t need = (size_t)5 * M * cv.cout;
+    if (tiles < 512 && scratch && need <= scratch_floats && cv.cout % 4 == 0) {
+        g.nseg = 1;
+        g.seg[0] = ASeg{x, ldx, -2, cv.cin, cv.cin_pad};
+        g.shift_z = 1;                               // tap z reads rows m + z - 2
+        g.strideBz = cv.cin_pad;                     // and the z-th K slice of the weight rows
+        g.act = ACT_NONE;
+        g.out0 = scratch;
+        g.strideOutZ = (long long)M * cv.cout;
+        HIPCHK(e, gemm_small(g, 5, e->stream));
+        const long long total4 = (long long)M * cv.cout / 4;
+        hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, e->stream, scratch,
+                           (long long)M * cv.cout, 5, cv.bias, cv.altbias, rowmask, mask_out, act, out, cv.cout, total4);
+        HIPCHK(e, hipGetLastError());
+        return TTS_HIP_OK;
+    }
+    g.nseg = 5;
+    for (int tap = 0; tap < 5; ++tap) g.seg[tap] = ASeg{x, ldx, tap - 2, cv.cin, cv.cin_pad};
+    g.bias = cv.bias;
+    g.act = act;
+    g.out0 = out;
     g.rowmask = rowmask;
     g.altbias = cv.altbias;
     g.mask_out = mask_out;
@@ -1126,6 +1169,8 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
     sz(RD * NMEL, 4); sz(RD, 4); sz(RD * Tin, 4); sz(RD, 1); sz(RD * NMEL, 4); sz(RD * 512, 4); sz(RD * 512, 4);
     sz(RD * NMEL, 4); sz(RD * NMEL, 4);
+    const size_t conv_rows = (size_t)std::min<long long>(std::max(R, RD), 32768);     // 512 tiles x 64 rows at most
+    sz(5 * conv_rows * 512, 4);
     need += 4096;
     HIPCHK(e, tc.ws.ensure(need));
     Arena A;
@@ -1167,6 +1212,8 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     float* d_pb = A.take<float>(RD * 512);
     float* d_post = A.take<float>(RD * NMEL);
     float* d_mel = A.take<float>(RD * NMEL);
+    float* d_convtmp = A.take<float>(5 * conv_rows * 512);
+    const size_t convtmp_n = 5 * conv_rows * 512;
     if (A.off > A.cap) return set_err(e, TTS_HIP_ENOMEM, "tacotron2 workspace accounting error");
     const size_t zero_from = (char*)d_state - A.base, zero_to = (char*)d_dmask - A.base;
 
@@ -1195,7 +1242,7 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     float* xout = d_x1;
     for (int i = 0; i < 3; ++i) {
         // MaskedConv1D -> BN -> relu; rows at padded tokens are stored as zeros (they are only ever consumed masked)
-        if ((rc = conv_gemm(e, tc.enc_conv[i], xin, 512, xout, (int)R, Tin, d_mask, ACT_RELU, 1))) return rc;
+        if ((rc = conv_gemm(e, tc.enc_conv[i], xin, 512, xout, (int)R, Tin, d_mask, ACT_RELU, 1, d_convtmp, convtmp_n))) return rc;
         std::swap(xin, xout);
     }
     {
@@ -1360,11 +1407,11 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
         hipLaunchKernelGGL(dec_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_lengths, d_decout,
                            d_dmask, d_xm, max_len, RD);
         HIPCHK(e, hipGetLastError());
-        if ((rc = conv_gemm(e, tc.post_conv[0], d_xm, NMEL, d_pa, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
-        if ((rc = conv_gemm(e, tc.post_conv[1], d_pa, 512, d_pb, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
-        if ((rc = conv_gemm(e, tc.post_conv[2], d_pb, 512, d_pa, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
-        if ((rc = conv_gemm(e, tc.post_conv[3], d_pa, 512, d_pb, (int)RD, max_len, d_dmask, ACT_TANH, 1))) return rc;
-        if ((rc = conv_gemm(e, tc.post_conv[4], d_pb, 512, d_post, (int)RD, max_len, d_dmask, ACT_NONE, 0))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[0], d_xm, NMEL, d_pa, (int)RD, max_len, d_dmask, ACT_TANH, 1, d_convtmp, convtmp_n))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[1], d_pa, 512, d_pb, (int)RD, max_len, d_dmask, ACT_TANH, 1, d_convtmp, convtmp_n))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[2], d_pb, 512, d_pa, (int)RD, max_len, d_dmask, ACT_TANH, 1, d_convtmp, convtmp_n))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[3], d_pa, 512, d_pb, (int)RD, max_len, d_dmask, ACT_TANH, 1, d_convtmp, convtmp_n))) return rc;
+        if ((rc = conv_gemm(e, tc.post_conv[4], d_pb, 512, d_post, (int)RD, max_len, d_dmask, ACT_NONE, 0, d_convtmp, convtmp_n))) return rc;
         hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_decout, d_post, d_mel, n);
         HIPCHK(e, hipGetLastError());
     }
