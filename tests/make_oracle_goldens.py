@@ -3,7 +3,7 @@ seeded synthetic weights.  They pin the ORACLE aga
 a committed fixture to match (GPU test); they are not reference outputs -- WaveGlow / Tacotron2 parity stays "unpinned"
 with respect to the reference, which cannot run here.
 
-usage: python scripts/make_oracle_goldens.py
+usage: python tests/make_oracle_goldens.py
 """
 import hashlib
 import os
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, ROOT)
 from oracle import tacotron2_ref, waveglow_ref                      # noqa: E402
 from text_to_speech_amd import weights                              # noqa: E402

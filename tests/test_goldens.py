@@ -1,4 +1,4 @@
-"""Committed golden fixtures (tests/golden/oracle_*_small.npz, made by scripts/make_oracle_goldens.py).
+"""Committed golden fixtures (tests/golden/oracle_*_small.npz, made by tests/make_oracle_goldens.py).
 
 CPU: the numpy oracle still reproduces them on freshly synthesized weights (pins the oracle and the seeded weight
 generator against drift).  GPU: the HIP path, through the C ABI, matches the committed outputs within the north-star
