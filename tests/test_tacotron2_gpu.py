@@ -140,3 +140,18 @@ def test_fp16_lstm_weights_close_to_fp32_oracle(gpu_engine, taco_weights, taco_c
     assert err <= MEL_TOL_F16 and err_att <= MEL_TOL_F16
     assert np.abs(exact.mel - ref.mel).max() <= MEL_TOL < 1e3 * max(err, 1e-12)   # and the flag is not ignored
     assert not np.array_equal(out.mel, exact.mel)
+
+
+@pytest.mark.parametrize('Tin,lens,win', [(70, [70, 41], None), (130, [130, 97], 24), (300, [300, 257], None),
+                                           (515, [515, 64], 40)])
+def test_long_inputs_cover_every_attention_path(gpu_engine, taco_weights, taco_cfg, Tin, lens, win):
+    """Token counts above 64 / 256 / 512 exercise the strided lane loops of the attention kernels, the prefetch limit of
+    softmax_ctx (32 x 8 rows) with its tail loop, and the second 256-stride of the weight writer; BiLSTM runs Tin steps."""
+    from oracle import tacotron2_ref
+    tok = _tokens(2, Tin, lens, seed=Tin)
+    kw = {} if win is None else dict(attn_mask_win_len=win, attn_mask_offset=0.5)
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=6, early_stopping=False, **kw)
+    gkw = {} if win is None else dict(attn_mask_win_len=win, attn_mask_offset=win // 2)
+    out = gpu_engine.tacotron2_infer(tok, max_len=6, early_stopping=False, **gkw)
+    _check(out, ref)
+    assert np.all(out.attention_weights[1, :, lens[1]:] == 0)
