@@ -16,6 +16,8 @@
 // padding (144-B rows: conflict-free ds_read_b128, MI355X_MICROARCH.md LDS table).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 namespace ttsgemm {
@@ -550,11 +552,13 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
                 return hipErrorInvalidValue;
     }
     auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE, HALF, NBD>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // two engine handles may launch from two host threads (stream(overlap=True)): the flag is atomic, and setting the
+    // attribute twice is harmless
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     dim3 grid(numMt8 * numNt, 1, batch_z);
     hipLaunchKernelGGL(kern, grid, dim3(WR * WC * 64), lds, stream, g);

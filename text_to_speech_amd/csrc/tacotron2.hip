@@ -17,6 +17,7 @@
 // "stop as soon as every row has fired" semantics (:625-627) without a host round trip per step.
 #include "engine.h"
 
+#include <atomic>
 #include <type_traits>
 #include "gemm_f32.h"
 
@@ -893,11 +894,11 @@ hipError_t launch_lstm(hipStream_t s, const DecState* st, int j, const LstmDev& 
                        const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
     const size_t lds = (size_t)NBT * 256 * KS * sizeof(float);
     auto kern = lstm_step_kernel<KS, NBT, HW>;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<bool> attr{false};
+    if (!attr.load(std::memory_order_acquire)) {
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (er != hipSuccess) return er;
-        attr = true;
+        attr.store(true, std::memory_order_release);
     }
     const void* W = HW ? (const void*)L.W16 : (const void*)L.W;
     hipLaunchKernelGGL(kern, dim3(L.units / 4), dim3(256), lds, s, st, j, W, L.b, s0, n0, s1, n1, h_old, h_new,
