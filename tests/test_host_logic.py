@@ -245,6 +245,39 @@ def test_symbol_table_and_encoding():
 
 
 # ------------------------------------------------------------------ runtime seam
+def test_text_normalisation_known_answers():
+    """Known answers derived from the reference source (utils/text/numbers.py:249-271 order of substitutions, cleaners.py
+    complete_cleaners :296-342, abreviations/en.json); num2words conventions for the number words."""
+    from text_to_speech_amd.text import (english_cleaners, french_cleaners, number_to_words, number_to_words_fr,
+                                         ordinal_to_words, ordinal_to_words_fr)
+    en = english_cleaners
+    assert en('Dr. Smith paid $3.50 on the 21st.') == 'doctor smith paid three dollars, fifty cents on the twenty-first.'
+    assert en('St Mary') == 'saint mary'                               # abbreviations match without the dot too (:176-186)
+    assert en('3h 20min') == 'three hours and twenty minutes' and en('1h') == 'one hour'
+    assert en('12:30:05') == 'twelve hours and thirty minutes and five seconds'
+    assert en('50 km/h') == 'fifty kilometers per hour'
+    assert en('1,234,567') == 'one million, two hundred and thirty-four thousand, five hundred and sixty-seven'
+    assert en('3.14') == 'three punt fourteen' and en('0.05') == 'zero punt zero five'      # (sic) 'punt', numbers.py:18-20
+    assert en('100% & more') == 'one hundred percent and more'
+    assert en('-5 + 3 = -2') == 'minus five plus three equal minus two'
+    assert en('**bold** £20 naïve café') == 'bold twenty pounds naive cafe'
+    assert en('$1') == 'one dollar' and en('$0.01') == 'one cent' and en('10-5') == 'ten - five'
+    assert [ordinal_to_words(n) for n in (1, 2, 3, 5, 12, 20, 21, 100, 101)] == [
+        'first', 'second', 'third', 'fifth', 'twelfth', 'twentieth', 'twenty-first', 'one hundredth',
+        'one hundred and first']
+    assert number_to_words(1001) == 'one thousand and one' and number_to_words(110) == 'one hundred and ten'
+    fr = french_cleaners
+    assert fr('Il y a 91 chats et 1 200 oiseaux le 1er mai.') == \
+        'il y a quatre-vingt-onze chats et mille deux cents oiseaux le premier mai.'
+    assert fr('3,14') == 'trois virgule quatorze'                      # single comma = decimal in French (:196-203)
+    assert fr('Noël naïf à Liège') == 'noel nahif a liège'            # tremas rule; only âéèêîç survive (cleaners.py:52)
+    assert [number_to_words_fr(n) for n in (21, 70, 71, 80, 81, 99, 100, 200, 201, 1000, 2000, 80000, 1000000)] == [
+        'vingt et un', 'soixante-dix', 'soixante et onze', 'quatre-vingts', 'quatre-vingt-un', 'quatre-vingt-dix-neuf',
+        'cent', 'deux cents', 'deux cent un', 'mille', 'deux mille', 'quatre-vingt mille', 'un million']
+    assert [ordinal_to_words_fr(n) for n in (1, 2, 4, 5, 9, 21)] == ['premier', 'deuxième', 'quatrième', 'cinquième',
+                                                                      'neuvième', 'vingt et unième']
+
+
 def test_build_runtime_registry_errors():
     from text_to_speech_amd.runtime import Runtime, HipRuntime, build_runtime, _runtimes
     assert _runtimes == {'hip': HipRuntime} and issubclass(HipRuntime, Runtime)

@@ -4,8 +4,11 @@ Restates the parts of /root/reference/utils/text that `Tacotron2.infer` needs (m
   symbol tables            utils/text/__init__.py:28-55   (en: '_' '-' "!'(),.:;? " A-Z a-z + 84 ARPAbet = 148 ids)
   english / french cleaners utils/text/cleaners.py:296-345 (lowercase, abbreviations, numbers -> words, whitespace)
   sentence splitting        utils/text/text_processing.py:34,228
-`num2words` / `unidecode` are not installed here, so numbers are spelled by the small English speller below and
-accents are folded with unicodedata; the character->id mapping itself is exactly the reference table.
+  number normalisation     utils/text/numbers.py:249-271  (units, math symbols, durations, clocks, currencies, decimals,
+                                                           ordinals, cardinals -- same order of substitutions)
+`num2words` / `unidecode` are not installed here: cardinals / ordinals are spelled by the English and French spellers
+below in num2words' conventions, and ASCII folding uses unicodedata plus a small ligature table; the character->id
+mapping itself is exactly the reference table.
 """
 from __future__ import annotations
 
@@ -28,17 +31,32 @@ _cmudict_symbols = [
 en_symbols = [_pad] + list(_special) + list(_punctuation) + list(_letters) + ['@' + s for s in _cmudict_symbols]
 fr_symbols = [_pad] + list(_special) + list(_punctuation) + list(_letters) + list(_accents)
 
-_abbreviations = [(re.compile(r'\b%s\.' % a, re.IGNORECASE), b) for a, b in [
-    ('mrs', 'misess'), ('mr', 'mister'), ('dr', 'doctor'), ('st', 'saint'), ('co', 'company'), ('jr', 'junior'),
-    ('maj', 'major'), ('gen', 'general'), ('drs', 'doctors'), ('rev', 'reverend'), ('lt', 'lieutenant'),
-    ('hon', 'honorable'), ('sgt', 'sergeant'), ('capt', 'captain'), ('esq', 'esquire'), ('ltd', 'limited'),
-    ('col', 'colonel'), ('ft', 'fort')]]
+# ---- abbreviations (utils/text/abreviations/en.json; replaced with or without the dot: cleaners.py:176-186) -------------
+_abbreviations_en = {
+    'mrs': 'misess', 'mr': 'mister', 'dr': 'doctor', 'st': 'saint', 'co': 'company', 'jr': 'junior', 'maj': 'major',
+    'gen': 'general', 'drs': 'doctors', 'rev': 'reverend', 'lt': 'lieutenant', 'hon': 'honorable', 'sgt': 'sergeant',
+    'capt': 'captain', 'esq': 'esquire', 'ltd': 'limited', 'col': 'colonel', 'ft': 'fort', 'tf': 'tensorflow'}
+_abbrev_re = {'en': re.compile(r'\b(%s)(\.|\b)' % '|'.join(sorted(_abbreviations_en, key=len, reverse=True)),
+                               re.IGNORECASE)}
+
+
+def expand_abbreviations(text: str, lang: str = 'en') -> str:
+    regex = _abbrev_re.get(lang)
+    if regex is None:
+        return text
+    return regex.sub(lambda m: _abbreviations_en[m.group(1).lower()], text)
+
+
+# ---- numbers -> words (the reference delegates to `num2words`, numbers.py:96-132; same conventions restated here) ------
 _ones = ['zero', 'one', 'two', 'three', 'four', 'five', 'six', 'seven', 'eight', 'nine', 'ten', 'eleven', 'twelve',
          'thirteen', 'fourteen', 'fifteen', 'sixteen', 'seventeen', 'eighteen', 'nineteen']
 _tens = ['', '', 'twenty', 'thirty', 'forty', 'fifty', 'sixty', 'seventy', 'eighty', 'ninety']
+_ord_irregular = {'one': 'first', 'two': 'second', 'three': 'third', 'five': 'fifth', 'eight': 'eighth', 'nine': 'ninth',
+                  'twelve': 'twelfth'}
 
 
 def number_to_words(n: int) -> str:
+    """English cardinal, num2words style: 'one thousand, two hundred and thirty-four'."""
     if n < 0:
         return 'minus ' + number_to_words(-n)
     if n < 20:
@@ -47,7 +65,7 @@ def number_to_words(n: int) -> str:
         return _tens[n // 10] + ('-' + _ones[n % 10] if n % 10 else '')
     if n < 1000:
         return _ones[n // 100] + ' hundred' + (' and ' + number_to_words(n % 100) if n % 100 else '')
-    for value, name in ((10 ** 9, 'billion'), (10 ** 6, 'million'), (1000, 'thousand')):
+    for value, name in ((10 ** 12, 'trillion'), (10 ** 9, 'billion'), (10 ** 6, 'million'), (1000, 'thousand')):
         if n >= value:
             rest = n % value
             return number_to_words(n // value) + ' ' + name + ((', ' if rest >= 100 else ' and ') +
@@ -55,28 +73,253 @@ def number_to_words(n: int) -> str:
     return str(n)
 
 
-def _expand_numbers(text: str) -> str:
-    text = re.sub(r'(\d),(\d{3})', r'\1\2', text)
-    text = re.sub(r'(\d+)\.(\d+)', lambda m: number_to_words(int(m.group(1))) + ' point ' +
-                  ' '.join(_ones[int(c)] for c in m.group(2)), text)
-    return re.sub(r'\d+', lambda m: number_to_words(int(m.group(0))), text)
+def ordinal_to_words(n: int) -> str:
+    words = number_to_words(n)
+    head, sep, last = words.rpartition('-') if '-' in words.split(' ')[-1] else words.rpartition(' ')
+    if last in _ord_irregular:
+        last = _ord_irregular[last]
+    elif last.endswith('y'):
+        last = last[:-1] + 'ieth'
+    else:
+        last += 'th'
+    return head + sep + last
 
 
-def english_cleaners(text: str) -> str:
-    text = unicodedata.normalize('NFKD', text).encode('ascii', 'ignore').decode('ascii')
-    text = text.lower()
-    text = _expand_numbers(text)
-    for regex, repl in _abbreviations:
-        text = regex.sub(repl, text)
+_fr_units = ['zéro', 'un', 'deux', 'trois', 'quatre', 'cinq', 'six', 'sept', 'huit', 'neuf', 'dix', 'onze', 'douze',
+             'treize', 'quatorze', 'quinze', 'seize', 'dix-sept', 'dix-huit', 'dix-neuf']
+_fr_tens = {20: 'vingt', 30: 'trente', 40: 'quarante', 50: 'cinquante', 60: 'soixante', 80: 'quatre-vingt'}
+
+
+def number_to_words_fr(n: int) -> str:
+    """French cardinal, num2words style: 'quatre-vingt-onze', 'deux cents', 'mille deux cent un'."""
+    if n < 0:
+        return 'moins ' + number_to_words_fr(-n)
+    if n < 20:
+        return _fr_units[n]
+    if n < 100:
+        ten = n // 10 * 10
+        if ten in (70, 90):
+            ten -= 10
+        unit = n - ten
+        base = _fr_tens[ten]
+        if unit == 0:
+            return base + ('s' if ten == 80 else '')
+        if unit in (1, 11) and ten != 80:
+            return base + ' et ' + _fr_units[unit]
+        return base + '-' + _fr_units[unit]
+    if n < 1000:
+        h, rest = divmod(n, 100)
+        head = 'cent' if h == 1 else _fr_units[h] + ' cent'
+        if rest == 0:
+            return head + ('s' if h > 1 else '')
+        return head + ' ' + number_to_words_fr(rest)
+    if n < 10 ** 6:
+        k, rest = divmod(n, 1000)
+        head = 'mille' if k == 1 else number_to_words_fr(k).removesuffix('s') + ' mille' if k % 100 == 80 or k % 100 == 0 and k >= 200 \
+            else number_to_words_fr(k) + ' mille'
+        return head + (' ' + number_to_words_fr(rest) if rest else '')
+    for value, name in ((10 ** 9, 'milliard'), (10 ** 6, 'million')):
+        if n >= value:
+            k, rest = divmod(n, value)
+            head = number_to_words_fr(k) + ' ' + name + ('s' if k > 1 else '')
+            return head + (' ' + number_to_words_fr(rest) if rest else '')
+    return str(n)
+
+
+def ordinal_to_words_fr(n: int) -> str:
+    if n == 1:
+        return 'premier'
+    w = number_to_words_fr(n)
+    if w.endswith('e'):
+        w = w[:-1]
+    elif w.endswith('f'):
+        w = w[:-1] + 'v'
+    elif w.endswith('q'):
+        w += 'u'
+    elif w.endswith('s') and not w.endswith('trois'):
+        w = w[:-1]
+    return w + 'ième'
+
+
+def _cardinal(n, lang):
+    return number_to_words(int(n)) if lang == 'en' else number_to_words_fr(int(n))
+
+
+def _ordinal(n, lang):
+    return ordinal_to_words(int(n)) if lang == 'en' else ordinal_to_words_fr(int(n))
+
+
+# tables of numbers.py:18-75
+_comma_word = {'fr': 'virgule', 'en': 'punt'}                      # (sic) the reference says 'punt' for the decimal point
+_math_words = {'=': {'fr': 'égal', 'en': 'equal'}, '+': {'fr': 'plus', 'en': 'plus'}, '-': {'fr': 'moins', 'en': 'minus'},
+               '*': {'fr': 'fois', 'en': 'times'}, '/': {'fr': 'divisé par', 'en': 'divide by'},
+               '^': {'fr': 'exposant', 'en': 'exponent'}}
+_time_words = {'h': {'fr': 'heure', 'en': 'hour'}, 'min': {'fr': 'minute', 'en': 'minute'},
+               'sec': {'fr': 'seconde', 'en': 'second'}, 's': {'fr': 'seconde', 'en': 'second'}}
+_time_sep = {'fr': ' et ', 'en': ' and '}
+_units = {'l': {'fr': 'litre', 'en': 'litre'}, 'g': {'fr': 'gramme', 'en': 'gram'}, 't': {'fr': 'tonne', 'en': 'tonne'},
+          'm': {'fr': 'mètre', 'en': 'meter'}, 'mi': {'fr': 'mile', 'en': 'mile'}, 'o': {'fr': 'octet', 'en': 'bytes'},
+          'b': {'fr': 'bar', 'en': 'bar'}, 'V': {'fr': 'volt', 'en': 'volt'}, 'W': {'fr': 'watt', 'en': 'watt'},
+          'A': {'fr': 'ampère', 'en': 'ampere'}, 'Hz': {'fr': 'hertz', 'en': 'hertz'}, 'J': {'fr': 'joule', 'en': 'joul'},
+          'N': {'fr': 'newton', 'en': 'newton'}}
+_unit_prefix = {'n': {'fr': 'nano', 'en': 'nano'}, 'm': {'fr': 'mili', 'en': 'mili'}, 'c': {'fr': 'centi', 'en': 'centi'},
+                'd': {'fr': 'déci', 'en': 'deci'}, 'k': {'fr': 'kilo', 'en': 'kilo'}, 'M': {'fr': 'méga', 'en': 'mega'},
+                'G': {'fr': 'giga', 'en': 'giga'}, 'T': {'fr': 'tera', 'en': 'tera'}}
+_units_sep = {'fr': 'par', 'en': 'per'}
+_units_re = re.compile(r'(\d+)\s*(%s)?(%s)(?:\/(%s))\b' % ('|'.join(_unit_prefix), '|'.join(_units), '|'.join(_time_words)))
+_math_symbol_re = re.compile(r'(?:(?<=\d)(\s*[\+\*\/\^\=]\s*(\+|\-\s*)?)(?=\d)|((?:^|\s+)(\-|\+)\s*(\+|\-\s*)?)(?=\d))')
+_sec_pat = r'(\d+)\s*(?:sec|s)\b'
+_min_pat = r'(\d+)\s*min(?:\s*%s)?' % _sec_pat
+_hours_pat = r'(\d+)\s*h\s*(?:%s|%s)?' % (_min_pat, _sec_pat)
+_time_re = re.compile(r'\b(?:%s|%s|%s)\b' % (_hours_pat, _min_pat, _sec_pat))
+_clock_re = re.compile(r'(\d{1,2}):(\d{1,2}):(\d{1,2})')
+_comma_number_re = re.compile(r'([0-9][0-9\,]+[0-9])')
+_space_number_re = re.compile(r'[0-9]+( [0-9]{3,3})+(?!\d)')
+_tiret_number_re = re.compile(r'([0-9]+-[0-9])')
+_pounds_re = re.compile(r'£([0-9\,]*[0-9]+)')
+_dollars_re = re.compile(r'\$([0-9\.\,]*[0-9]+)')
+_decimal_number_re = re.compile(r'([0-9]+\.[0-9]+)')
+_number_re = re.compile(r'[0-9]+')
+_ordinal_re = re.compile(r'([0-9]+)(st|nd|rd|th|er|ère|ème|eme|ième|ieme)')
+
+
+def _expand_units(m, lang):
+    n, prefix, unit, per_time = m.groups()
+    if n == '1' and lang == 'fr' and unit == 't':
+        n = 'une'
+    text = n + ' ' + (_unit_prefix[prefix][lang] if prefix else '') + _units[unit][lang]
+    if n != 'une' and n > '1':
+        text += 's'
+    if per_time:
+        text += ' ' + _units_sep[lang] + ' ' + _time_words[per_time][lang]
+    return text
+
+
+def _expand_hms(parts, lang):
+    out = []
+    for t, unit in parts:
+        if t is None:
+            continue
+        word = _time_words[unit][lang]
+        if int(t) > 1:
+            word += 's'
+        elif lang == 'fr' and int(t) == 1:
+            t = 'une'
+        out.append('{} {}'.format(t, word))
+    return _time_sep[lang].join(out)
+
+
+def _expand_time(m, lang):
+    g = m.groups()
+    return _expand_hms(((g[0], 'h'), (g[1] or g[4], 'min'), (g[2] or g[3] or g[5] or g[6], 'sec')), lang)
+
+
+def _expand_dollars(m):
+    parts = m.group(1).split('.')
+    if len(parts) > 2:
+        return m.group(1) + ' dollars'
+    dollars = int(parts[0].replace(',', '')) if parts[0] else 0
+    cents = int(parts[1]) if len(parts) > 1 and parts[1] else 0
+    if dollars and cents:
+        return '{} dollar{}, {} cent{}'.format(dollars, 's' if dollars != 1 else '', cents, 's' if cents != 1 else '')
+    if dollars:
+        return '{} dollar{}'.format(dollars, 's' if dollars != 1 else '')
+    if cents:
+        return '{} cent{}'.format(cents, 's' if cents != 1 else '')
+    return 'zero dollars'
+
+
+def _extend_with_zeros(text, lang):
+    n = len(text) - len(text.lstrip('0'))
+    words = _cardinal(text, lang)
+    if n == 0:
+        return words
+    if n < 4:
+        return ' '.join([_cardinal(0, lang)] * n + [words])
+    return '{} {} {} {}'.format(_cardinal(n, lang), _math_words['*'][lang], _cardinal(0, lang), words)
+
+
+def _expand_number(m, lang):
+    num = m.group(0)
+    if '.' not in num:
+        return _cardinal(num, lang)
+    ent, dec = num.split('.')
+    if dec.count('0') == len(dec):
+        return _cardinal(ent, lang)
+    return '{} {} {}'.format(_cardinal(ent, lang), _comma_word[lang], _extend_with_zeros(dec, lang))
+
+
+def normalize_numbers(text: str, lang: str = 'en', expand_symbols: bool = True) -> str:
+    """Restatement of numbers.py:249-271, same order of substitutions."""
+    if expand_symbols:
+        text = _units_re.sub(lambda m: _expand_units(m, lang), text)
+        text = _math_symbol_re.sub(lambda m: ' ' + ' '.join(_math_words[s][lang] for s in m.group(0).split()) + ' ', text)
+    text = _time_re.sub(lambda m: _expand_time(m, lang), text)
+    text = _clock_re.sub(lambda m: _expand_hms(zip(m.groups(), ('h', 'min', 'sec')), lang), text)
+    text = _comma_number_re.sub(lambda m: m.group(1).replace(',', '.') if lang == 'fr' and m.group(1).count(',') == 1
+                                else m.group(1).replace(',', ''), text)
+    text = _tiret_number_re.sub(lambda m: m.group(1).replace('-', ' - '), text)
+    text = _space_number_re.sub(lambda m: m.group(0).replace(' ', ''), text)
+    text = _pounds_re.sub(r'\1 pounds', text)
+    text = _dollars_re.sub(_expand_dollars, text)
+    text = _decimal_number_re.sub(lambda m: _expand_number(m, lang), text)
+    text = _ordinal_re.sub(lambda m: _ordinal(m.group(1), lang), text)
+    return _number_re.sub(lambda m: _expand_number(m, lang), text)
+
+
+# ---- special symbols, tremas, ascii folding (cleaners.py:188-201,263-277; numbers.py:273-284) -----------------------------
+_special_symbols = {'=': {'fr': 'égal', 'en': 'equal'}, '+': {'fr': 'plus', 'en': 'plus'}, '/': {'fr': 'slash', 'en': 'slash'},
+                    '^': {'fr': 'chapeau', 'en': 'hat'}, '%': {'fr': 'pourcent', 'en': 'percent'},
+                    '§': {'fr': 'paragraphe', 'en': 'paragraph'}, '&': {'fr': 'et', 'en': 'and'},
+                    '°C': {'fr': 'degrés', 'en': 'degrees'}, '°': {'fr': 'degrés', 'en': 'degrees'}}
+
+
+def expand_special_symbols(text: str, lang: str) -> str:
+    for symbol, words in _special_symbols.items():
+        text = text.replace(symbol, ' ' + words[lang] + ' ')
+    return text
+
+
+def _to_ascii(text: str) -> str:
+    """`unidecode` stand-in (not installed here): canonical decomposition, combining marks dropped, a few ligatures and
+    typographic quotes / dashes mapped by hand."""
+    table = {'œ': 'oe', 'Œ': 'OE', 'æ': 'ae', 'Æ': 'AE', 'ß': 'ss', '’': "'", '‘': "'", '“': '"', '”': '"', '–': '-',
+             '—': '-', '…': '...', '«': '<<', '»': '>>'}
+    text = ''.join(table.get(c, c) for c in text)
+    return unicodedata.normalize('NFKD', text).encode('ascii', 'ignore').decode('ascii')
+
+
+def complete_cleaners(text: str, lang: str, *, to_lowercase=True, to_expand=True, to_expand_abrev=True,
+                      to_expand_symbols=True, **_) -> str:
+    """Restatement of cleaners.py:296-342 (acronym expansion, replacements and repetition collapsing: not needed by the
+    TTS models' default pipeline)."""
+    if to_lowercase:
+        text = text.lower()
+    if to_expand:
+        text = re.sub(r'\*\*(.*)\*\*', r'\1', text)                           # remove_markdown
+        if to_expand_abrev:
+            text = expand_abbreviations(text, lang)
+        text = normalize_numbers(text, lang if lang != 'be' else 'fr', expand_symbols=to_expand_symbols)
+        if to_expand_symbols:
+            text = expand_special_symbols(text, lang if lang != 'be' else 'fr')
+    if lang in ('fr', 'be'):
+        text = re.sub(r'(ï)', 'hi', re.sub('(aï)\b', 'aille', text))               # expand_tremas (sic: '\b' is a backspace there)
+        keep = set(_accents_kept)
+        text = ''.join(c if c in keep else _to_ascii(c) for c in text)
+    else:
+        text = _to_ascii(text)
     return re.sub(r'\s+', ' ', text).strip()
 
 
-def french_cleaners(text: str) -> str:
-    text = text.lower()
-    keep = set(_accents)
-    text = ''.join(c if c in keep else unicodedata.normalize('NFKD', c).encode('ascii', 'ignore').decode('ascii')
-                   for c in text)
-    return re.sub(r'\s+', ' ', text).strip()
+_accents_kept = 'âéèêîç'                                            # cleaners.py:52
+
+
+def english_cleaners(text: str, **kwargs) -> str:
+    return complete_cleaners(text, 'en', **kwargs)
+
+
+def french_cleaners(text: str, **kwargs) -> str:
+    return complete_cleaners(text, 'fr', **kwargs)
 
 
 def split_sentences(text: str):
@@ -117,8 +360,9 @@ class CharTokenizer:
     def vocab_size(self):
         return len(self.symbols)
 
-    def clean_text(self, text, **_):
-        return self.cleaner(text)
+    def clean_text(self, text, **kwargs):
+        allowed = ('to_lowercase', 'to_expand', 'to_expand_abrev', 'to_expand_symbols')
+        return self.cleaner(text, **{k: v for k, v in kwargs.items() if k in allowed})
 
     def encode(self, text, cleaned=False):
         if not cleaned:
