@@ -372,7 +372,12 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         const float* b = Bs + buf * BN * LDSK + (wc * CT * 32 + li) * LDSK + koff;
         f32x4 fa[RT], fb[CT];
 #pragma unroll
-        for (int i = 0; i < RT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
+        for (int i = 0; i < RT; ++i) {
+#ifdef TTS_ABL
+            if (HALF && (TTS_ABL == 5 || TTS_ABL == 6)) { fa[i] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(i + k8); continue; }   // ablation: no A-side LDS reads
+#endif
+            fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
+        }
 #pragma unroll
         for (int j = 0; j < CT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK);
         if constexpr (HALF) {
@@ -399,12 +404,19 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         // NBUF (3 or 4) LDS buffers.  Step t: issue tile t+NBUF-1's DMA into the buffer read at step t-1 (every wave has
         // passed the barrier that ended that step), run tile t's MFMAs, then wait until all but the newest NBUF-2 tiles'
         // DMA have landed (counted vmcnt: tile t+1 is in LDS) and barrier.  No VGPR staging, no ds_write.
+#ifdef TTS_ABL
+        constexpr int LT = (HALF && (TTS_ABL == 4 || TTS_ABL == 6)) ? PB : PA + PB;
+#else
         constexpr int LT = PA + PB;                  // DMA instructions per tile per wave
+#endif
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         auto dma_tile = [&](int buf) {
             fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff) {
                 // wave-uniform LDS base of this instruction's 16 rows; lane l lands at base + 16 * l
                 float* dst = (isA ? As + buf * BM * LDSK : Bs + buf * BN * LDSK) + (p * RPP + wave * 16) * LDSK;
+#ifdef TTS_ABL
+                if (HALF && (TTS_ABL == 4 || TTS_ABL == 6) && isA) return;       // ablation: no A-side DMA
+#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
             });
         };
