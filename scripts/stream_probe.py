@@ -13,6 +13,7 @@ from text_to_speech_amd.waveglow import WaveGlow
 
 prec = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 n_sent = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+sampled = len(sys.argv) > 3 and sys.argv[3] == 'sampled'      # prenet dropout masks + WaveGlow noise sampled per call
 e1, e2 = HipEngine(0), HipEngine(0)
 tw, ww = weights.synth_tacotron2(Tacotron2Config(), seed=1234), weights.synth_waveglow(WaveGlowConfig())
 for e in (e1, e2):
@@ -24,11 +25,11 @@ rng = np.random.default_rng(0)
 letters = np.array(list('abcdefghijklmnopqrstuvwxyz     '))
 lens = [50, 70, 90, 110, 130, 150, 170, 200]
 texts = [''.join(rng.choice(letters, lens[i % 8])).strip() + f' {i}.' for i in range(n_sent)]
-kw = dict(max_length=4., deterministic=True, save=False, return_results=False)
+kw = dict(max_length=4., deterministic=not sampled, save=False, return_results=False)
 model.predict(texts[:2], vocoder=voc_same, **kw); model.predict(texts[:2], vocoder=voc_own, overlap=True, **kw)
 for name, v, ov in (('sequential', voc_same, False), ('overlapped', voc_own, True)):
     secs = []
     t0 = time.perf_counter()
     model.predict(texts, vocoder=v, overlap=ov, callbacks=[lambda time, **_: secs.append(time)], **kw)
     dt = time.perf_counter() - t0
-    print(f'{name} [{prec}]: {n_sent} sentences, {sum(secs):.1f} s of audio in {dt*1e3:.0f} ms = {sum(secs)/dt:.0f}x real time', flush=True)
+    print(f'{name} [{prec}{", sampled" if sampled else ""}]: {n_sent} sentences, {sum(secs):.1f} s of audio in {dt*1e3:.0f} ms = {sum(secs)/dt:.0f}x real time', flush=True)

@@ -32,7 +32,8 @@ class TTSPipeline:
         max_len = int(np.float32(n_tok) * np.float32(max_length)) if isinstance(max_length, float) else int(max_length)
         max_len = max(1, max_len)
         if prenet_masks is None and not deterministic:
-            prenet_masks = (self._rng.random((B, max_len, 2, 256)) >= 0.5).astype(np.float32) * np.float32(2.0)
+            from .runtime import sample_prenet_masks
+            prenet_masks = sample_prenet_masks(self._rng, B, max_len)
         if prenet_masks is not None:
             prenet_masks = torch.as_tensor(prenet_masks, dtype=torch.float32).to(dev)
         if speaker is not None:
