@@ -73,6 +73,13 @@ int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, co
 int tts_hip_waveglow_infer_f16(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
                                float* audio, int mem);
 
+/* Same contract in split-fp16 arithmetic: every GEMM operand (activations, mel, weights) is held as two fp16 planes
+ * hi = fp16(v), lo = fp16(v - hi) (~22 significant bits) and a product is the three MFMAs hi*hi + hi*lo + lo*hi
+ * accumulated in fp32 -- the "3x" emulation of fp32 GEMM on half-precision matrix cores: fp32-class results (waveform RMS
+ * error ~1e-6 against the fp32 oracle) at 3/16 of the fp32 MFMA cost.  Everything outside the GEMM operands is fp32.      */
+int tts_hip_waveglow_infer_f16x3(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                                 float* audio, int mem);
+
 /* ---- Tacotron2.infer  (architectures/tacotron2_arch.py:866-925; called at models/tts/tacotron2.py:162)
  * tokens        int32 [B, Tin], 0 = pad
  * speaker       NULL or [B, speaker_embedding_dim]

@@ -125,3 +125,29 @@ def test_waveglow_config2_rows_equal_batch1_runs(gpu_engine):
         assert rms(single[0] - full[b]) <= 5e-6
         single16 = gpu_engine.waveglow_infer(mel[b:b + 1], z=z[b:b + 1], precision='f16')
         assert rms(single16[0] - full16[b]) <= 5e-5      # fp16 rounding of differently-ordered fp32 sums
+
+
+# ---- split-fp16 mode (tts_hip_waveglow_infer_f16x3): three fp16 MFMAs per product on (hi, lo) operand planes --------------
+# ~22 operand bits and fp32 accumulation: the SAME tolerance as the exact fp32 path applies (measured 4.4e-7 RMS against the
+# exact-fp32 kernels, i.e. the level of fp32 rounding itself).
+@pytest.mark.parametrize('B,T', [(1, 8), (2, 13), (1, 100), (2, 128)])
+def test_waveglow_f16x3_matches_oracle_at_fp32_tolerance(gpu_engine, wg_weights, wg_cfg, B, T):
+    from oracle import waveglow_ref
+    mel, z = _inputs(B, T, seed=61)
+    ref = waveglow_ref.infer(mel, wg_weights, wg_cfg, z=z, sigma=1.0)
+    out = gpu_engine.waveglow_infer(mel, z=z, sigma=1.0, precision='f16x3')
+    exact = gpu_engine.waveglow_infer(mel, z=z, sigma=1.0)
+    err = rms(out - ref)
+    print(f'f16x3 B={B} T={T} rms_err={err:.3e} (exact fp32 path: {rms(exact - ref):.3e}; x3 vs exact {rms(out - exact):.3e})')
+    assert out.shape == ref.shape and np.isfinite(out).all() and err <= RMS_TOL
+    assert not np.array_equal(out, exact)                              # a different arithmetic, not the flag ignored
+
+
+def test_waveglow_f16x3_config2_close_to_exact_path(gpu_engine):
+    """Full BASELINE config 2 shape (256 x 256 tiles, two LDS buffers): against the exact-fp32 kernels and batch-1 rows."""
+    mel, z = _inputs(8, 800, seed=71)
+    exact = gpu_engine.waveglow_infer(mel, z=z)
+    out = gpu_engine.waveglow_infer(mel, z=z, precision='f16x3')
+    assert np.isfinite(out).all() and rms(out - exact) <= 5e-6
+    single = gpu_engine.waveglow_infer(mel[3:4], z=z[3:4], precision='f16x3')
+    assert rms(single[0] - out[3]) <= 5e-6

@@ -49,6 +49,9 @@ struct WgLayerDev {
     _Float16* in_Bt16 = nullptr;    // fp16 operands of the optional fp16 path (built on first use): [1024][1536] (taps in
     _Float16* cond_Bt16 = nullptr;  //   chunks of 32), [32][1024][4*96], [512][512]
     _Float16* rs_Bt16 = nullptr;
+    _Float16* in_Bt_x3 = nullptr;   // split-fp16 mode: the same three matrices as [2 planes][...] (hi, lo), built on first use
+    _Float16* cond_Bt_x3 = nullptr;
+    _Float16* rs_Bt_x3 = nullptr;
     float* rs_Bt = nullptr;     // [512][512] residual half of res_skip (layers 0..6)
     float* rs_bias = nullptr;   // [512]
     int rs_n = 0;
@@ -67,7 +70,7 @@ struct WaveGlowDev {
     WgFlowDev flow[12];
     std::vector<void*> allocs;
     DevBuf x, acts, audio, a0p, io_mel, io_z, io_out;
-    bool f16_ready = false;
+    bool f16_ready = false, x3_ready = false;
     DevBuf x16, acts16, a0p16, mel16;        // fp16 path: shadow of x, activations, first-layer operand, mel
 };
 

@@ -71,7 +71,7 @@ void timing_collect(tts_hip_engine* e) {
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 3; }
+int tts_hip_abi_version(void) { return 4; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -248,6 +248,11 @@ int tts_hip_waveglow_infer(tts_hip_engine* e, const float* mel, int B, int T, co
 int tts_hip_waveglow_infer_f16(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
                                float* audio, int mem) {
     return waveglow_infer_impl(e, mel, B, T, z, sigma, audio, mem, 1);
+}
+
+int tts_hip_waveglow_infer_f16x3(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                                 float* audio, int mem) {
+    return waveglow_infer_impl(e, mel, B, T, z, sigma, audio, mem, 2);
 }
 
 int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem) {

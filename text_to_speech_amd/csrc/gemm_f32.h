@@ -41,6 +41,7 @@ struct ASeg {
     int k;              // valid K extent of this segment (multiple of 4)
     int kpad;           // K extent in Bt (multiple of BK, zero padded)
     int kind;           // SEG_ROWS / SEG_PHASE_TAP / SEG_FRAME
+    long long plane;    // PL == 2 kernels: offset (in floats) of the operand's second fp16 plane (the "lo" halves)
 };
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
@@ -70,6 +71,8 @@ struct GemmArgs {
     int split;                      // columns [0, split) -> out0, [split, N) -> out1 (col - split); split == N: single output
     float* out0; long long ld0; int acc0;     // accN: add to the existing value (read-modify-write)
     _Float16* out0h; long long ld0h;          // HALF kernels: fp16 output (gate) / fp16 shadow of out0 (linear); may be null
+    long long planeB, planeB2;                // PL == 2 kernels: second-plane offsets (in floats) of Bt and Bt2
+    long long planeOut;                       // PL == 2 kernels: second-plane offset (in halfs) of out0h
     float* out1; long long ld1; int acc1;
     long long strideOutZ;
     const uint8_t* rowmask;         // optional [M]: rows with mask 0 produce act(altbias[n]) instead
@@ -131,10 +134,13 @@ enum { PIPE_REG = 0, PIPE_DMA = 1 };
 // epilogue stores works on 4-byte units, so an fp16 operand is described to the kernel in "float units": ld, k, kpad, ldb
 // are HALF the element counts and one 16-byte LDS fragment (4 float units) carries 8 halfs = the K = 16 slice of one
 // MFMA -- the DMA pipeline, the swizzle and the segment addressing are shared with the fp32 kernel.
+// PL = 2 (fp16 only): every operand is a pair of fp16 planes (hi, lo) with v ~= hi + lo (22 significant bits), and a
+// product is the three MFMAs hi*hi + hi*lo + lo*hi accumulated in fp32 -- fp32-class accuracy at 3/16 of the fp32 MFMA cost.
 template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false,
-          int NBD = 3>
+          int NBD = 3, int PL = 1>
 __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmArgs g) {
     static_assert(!HALF || PIPE == PIPE_DMA, "fp16 operands use the LDS-DMA pipeline");
+    static_assert(PL == 1 || (PL == 2 && HALF), "two planes are the split-fp16 mode");
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
     constexpr bool DMA = PIPE == PIPE_DMA;
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     static_assert(BK == 16 || BK == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                          // [NBUF][BM][LDSK]
-    float* Bs = smem + NBUF * BM * LDSK;       // [NBUF][BN][LDSK]
+    float* As = smem;                          // [NBUF][PL][BM][LDSK]
+    float* Bs = smem + NBUF * PL * BM * LDSK;  // [NBUF][PL][BN][LDSK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -251,12 +257,14 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     // registers, refreshed only at a crossing
     int s_cur = NI, kc_cur = 0, kglob = 0, kglob2 = 0;
     int seg_k = 0, seg_kpad = 0;
+    unsigned seg_plane = 0;                          // byte offset of the current sequential segment's second plane
     __amdgpu_buffer_rsrc_t rsA;
     unsigned a_off[PA];
     auto enter_segment = [&]() {
         const ASeg sg = g.seg[s_cur];
         seg_k = sg.k;
         seg_kpad = sg.kpad;
+        seg_plane = (unsigned)(sg.plane * 4);
         long long abs_row;
         int vshift;
         seg_row(sg, abs_row, vshift);
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
                     const bool ok = kok && ((vmaskI[p] >> si) & 1u);
-                    emit(true, p, rsI, ok ? baseI[p] + delta : OOB);
+                    emit(true, p, rsI, ok ? baseI[p] + delta : OOB, (unsigned)(sg0.plane * 4));
                 }
                 if (++si == NI) {
                     si = 0;
@@ -345,8 +353,9 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             } else {
                 const unsigned kb = (unsigned)(kc_cur * BK * 4);
                 const bool kok = kc_cur * BK + c4 < seg_k;
+                const unsigned pl_a = seg_plane;     // (read before a segment crossing below may change it)
 #pragma unroll
-                for (int p = 0; p < PA; ++p) emit(true, p, rsA, kok ? a_off[p] + kb : OOB);
+                for (int p = 0; p < PA; ++p) emit(true, p, rsA, kok ? a_off[p] + kb : OOB, pl_a);
                 if (++kc_cur * BK >= seg_kpad) {
                     kc_cur = 0;
                     if (++s_cur < g.nseg) enter_segment();
@@ -356,8 +365,9 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             const bool use2 = B2 && !(NI > 0 && t_load < nI);
             const __amdgpu_buffer_rsrc_t rsW = make_rsrc_uniform(use2 ? bbase2 : bbase1);
             const unsigned kg = (unsigned)((use2 ? kglob2 : kglob) * 4);
+            const unsigned pl_b = (unsigned)((use2 ? g.planeB2 : g.planeB) * 4);
 #pragma unroll
-            for (int p = 0; p < PB; ++p) emit(false, p, rsW, (use2 ? b_off2[p] : b_off[p]) + kg);
+            for (int p = 0; p < PB; ++p) emit(false, p, rsW, (use2 ? b_off2[p] : b_off[p]) + kg, pl_b);
             if (use2) kglob2 += BK;
             else kglob += BK;
         }
@@ -368,8 +378,34 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     const int xr = (li >> 2) & 3;                    // DMA image: chunk XOR of this lane's operand rows
     auto compute_chunk = [&](int buf, int k8) {
         const int koff = DMA ? (((2 * k8 + lh) ^ xr) * 4) : (lh * 4 + k8 * 8);
-        const float* a = As + buf * BM * LDSK + (wr * RT * 32 + li) * LDSK + koff;
-        const float* b = Bs + buf * BN * LDSK + (wc * CT * 32 + li) * LDSK + koff;
+        const float* a = As + buf * PL * BM * LDSK + (wr * RT * 32 + li) * LDSK + koff;
+        const float* b = Bs + buf * PL * BN * LDSK + (wc * CT * 32 + li) * LDSK + koff;
+        if constexpr (PL == 2) {
+            f32x4 fa[RT], fal[RT], fb[CT], fbl[CT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
+                fal[i] = *reinterpret_cast<const f32x4*>(a + (BM + i * 32) * LDSK);
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK);
+                fbl[j] = *reinterpret_cast<const f32x4*>(b + (BN + j * 32) * LDSK);
+            }
+            // hi*lo and lo*hi first, hi*hi last: the small terms are added before the large one lands in the fp32 sum
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fal[i]),
+                                                                       __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]),
+                                                                       __builtin_bit_cast(f16x8, fbl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]),
+                                                                       __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+                }
+            return;
+        }
         f32x4 fa[RT], fb[CT];
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
@@ -405,19 +441,23 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         // passed the barrier that ended that step), run tile t's MFMAs, then wait until all but the newest NBUF-2 tiles'
         // DMA have landed (counted vmcnt: tile t+1 is in LDS) and barrier.  No VGPR staging, no ds_write.
 #ifdef TTS_ABL
-        constexpr int LT = (HALF && (TTS_ABL == 4 || TTS_ABL == 6)) ? PB : PA + PB;
+        constexpr int LT = PL * ((HALF && (TTS_ABL == 4 || TTS_ABL == 6)) ? PB : PA + PB);
 #else
-        constexpr int LT = PA + PB;                  // DMA instructions per tile per wave
+        constexpr int LT = PL * (PA + PB);           // DMA instructions per tile per wave
 #endif
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         auto dma_tile = [&](int buf) {
-            fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff) {
+            fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned pofs) {
                 // wave-uniform LDS base of this instruction's 16 rows; lane l lands at base + 16 * l
-                float* dst = (isA ? As + buf * BM * LDSK : Bs + buf * BN * LDSK) + (p * RPP + wave * 16) * LDSK;
+                float* dst = (isA ? As + buf * PL * BM * LDSK : Bs + buf * PL * BN * LDSK) + (p * RPP + wave * 16) * LDSK;
 #ifdef TTS_ABL
                 if (HALF && (TTS_ABL == 4 || TTS_ABL == 6) && isA) return;       // ablation: no A-side DMA
 #endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+                if constexpr (PL == 2) {             // the "lo" plane: same rows, second LDS image
+                    float* dst2 = dst + (isA ? BM : BN) * LDSK;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst2, 16, voff + pofs, 0, 0, 0);
+                }
             });
         };
         // prologue: NBUF - 1 tiles in flight (dma_tile is a no-op past the last tile, but still counts no instructions,
@@ -454,7 +494,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         // quarter of the MFMAs of tile t, write tile t+1 to the other LDS buffer, finish the MFMAs, barrier.
         f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
         auto load_next = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {
-            fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff) {
+            fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned) {
                 if (isA) ra[p] = buf_load4(rs, voff);
                 else rb[p] = buf_load4(rs, voff);
             });
@@ -504,8 +544,13 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                         const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
                         if (m < g.M) {
                             const float gv = gate_tanh_sigmoid(acc[i][2 * q][r], acc[i][2 * q + 1][r]);
-                            if constexpr (HALF) g.out0h[(long long)m * g.ld0h + ch] = (_Float16)gv;
-                            else out[(long long)m * g.ld0 + ch] = gv;
+                            if constexpr (HALF) {
+                                const _Float16 hv = (_Float16)gv;
+                                g.out0h[(long long)m * g.ld0h + ch] = hv;
+                                if constexpr (PL == 2) g.out0h[g.planeOut + (long long)m * g.ld0h + ch] = (_Float16)(gv - (float)hv);
+                            } else {
+                                out[(long long)m * g.ld0 + ch] = gv;
+                            }
                         }
                     }
                 }
@@ -532,7 +577,11 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                     const float ov = act_apply(v, g.act);
                     outp[(long long)m * ldo + nc] = ov;
                     if constexpr (HALF) {
-                        if (g.out0h && !second) g.out0h[(long long)m * g.ld0h + nc] = (_Float16)ov;
+                        if (g.out0h && !second) {
+                            const _Float16 hv = (_Float16)ov;
+                            g.out0h[(long long)m * g.ld0h + nc] = hv;
+                            if constexpr (PL == 2) g.out0h[g.planeOut + (long long)m * g.ld0h + nc] = (_Float16)(ov - (float)hv);
+                        }
                     }
                 }
             }
@@ -540,7 +589,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 }
 
 template <int WR, int WC, int RT, int CT, int BK, int OCC, int TAG, int NI = 0, int PIPE = PIPE_REG, bool HALF = false,
-          int NBD = 3>
+          int NBD = 3, int PL = 1>
 inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream) {
     constexpr int BM = WR * RT * 32;
     constexpr int BN = WC * CT * 32;
@@ -549,7 +598,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
     const int numNt = (g.N + BN - 1) / BN;
     const int numMt = (g.M + BM - 1) / BM;
     const int numMt8 = (numMt + 7) / 8 * 8;
-    const size_t lds = (size_t)NBUF * (BM + BN) * LDSK * sizeof(float);
+    const size_t lds = (size_t)NBUF * PL * (BM + BN) * LDSK * sizeof(float);
     if (g.split < g.N && g.split % BN != 0) return hipErrorInvalidValue;     // output side must be uniform per block
     if (g.phase_rows > 0) {
         // tiles must not straddle phases; the interleaved-tap descriptor spans at most the whole operand (31-bit offsets)
@@ -560,10 +609,10 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
         if (g.nseg < NI) return hipErrorInvalidValue;
         for (int i = 1; i < NI; ++i)
             if (g.seg[i].k != g.seg[0].k || g.seg[i].kpad != g.seg[0].kpad || g.seg[i].ptr != g.seg[0].ptr ||
-                g.seg[i].ld != g.seg[0].ld)
+                g.seg[i].ld != g.seg[0].ld || g.seg[i].plane != g.seg[0].plane)
                 return hipErrorInvalidValue;
     }
-    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE, HALF, NBD>;
+    auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE, HALF, NBD, PL>;
     // two engine handles may launch from two host threads (stream(overlap=True)): the flag is atomic, and setting the
     // attribute twice is harmless
     static std::atomic<bool> attr_set{false};
@@ -612,6 +661,21 @@ inline hipError_t gemm_wn_res_r64(const GemmArgs& g, hipStream_t s) { return lau
 inline hipError_t gemm_wn_in_r64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_IN, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
 inline hipError_t gemm_wn_in0_r64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true>(g, 1, s); }
 inline hipError_t gemm_wn_res_r64h(const GemmArgs& g, hipStream_t s) { return launch_gemm<2, 2, 1, 2, TTS_WN_BK, 4, TAG_WN_RES_SKIP, 0, PIPE_DMA, true>(g, 1, s); }
+// split-fp16 variants (two fp16 planes per operand, three MFMAs per product), 8 waves.  In-layer GEMM: 256 x 256 block tile
+// with TWO LDS buffers (131 KB; a K step carries 3x the MFMA work of the fp16 kernel, so one tile of prefetch covers the
+// latency: 2 142 us vs 2 429 us for 256 x 128 tiles with three buffers); 64 x 128 tiles for short utterances.
+inline hipError_t gemm_wn_in_x3(const GemmArgs& g, bool small, hipStream_t s) {
+    return small ? launch_gemm<2, 2, 1, 2, TTS_WN_BK, 2, TAG_WN_IN, WN_TAPS, PIPE_DMA, true, 3, 2>(g, 1, s)
+                 : launch_gemm<4, 2, 2, 4, TTS_WN_BK, 1, TAG_WN_IN, WN_TAPS, PIPE_DMA, true, 2, 2>(g, 1, s);
+}
+inline hipError_t gemm_wn_in0_x3(const GemmArgs& g, bool small, hipStream_t s) {
+    return small ? launch_gemm<2, 2, 1, 2, TTS_WN_BK, 2, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true, 3, 2>(g, 1, s)
+                 : launch_gemm<4, 2, 2, 2, TTS_WN_BK, 1, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true, 3, 2>(g, 1, s);
+}
+inline hipError_t gemm_wn_res_x3(const GemmArgs& g, bool small, hipStream_t s) {
+    return small ? launch_gemm<2, 2, 1, 2, TTS_WN_BK, 2, TAG_WN_RES_SKIP, 0, PIPE_DMA, true, 3, 2>(g, 1, s)
+                 : launch_gemm<4, 2, 2, 2, TTS_WN_BK, 1, TAG_WN_RES_SKIP, 0, PIPE_DMA, true, 3, 2>(g, 1, s);
+}
 // fp16-operand variants (activations and weights fp16 in HBM, fp32 accumulate): same tiles and pipeline
 #ifndef TTS_H_NBUF
 #define TTS_H_NBUF 3   // LDS buffers of that kernel (4 = three tiles in flight was measured no faster: 898 vs 855-885 us)

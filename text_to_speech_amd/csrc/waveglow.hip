@@ -103,34 +103,41 @@ __global__ void cond_bias_kernel(const float* __restrict__ wct, const float* __r
 }
 
 // ---- fp16 operand builders (run once, on first use of the fp16 path, from the packed fp32 device copies)
-__global__ void cvt_half_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n) {
+// `lo` (may be null) receives the second plane of the split-fp16 mode: lo = fp16(v - fp16(v))
+__device__ __forceinline__ void put_split(_Float16* dst, _Float16* lo, long long i, float v) {
+    const _Float16 hv = (_Float16)v;
+    dst[i] = hv;
+    if (lo) lo[i] = (_Float16)(v - (float)hv);
+}
+__global__ void cvt_half_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n,
+                                _Float16* __restrict__ lo = nullptr) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = (_Float16)src[i];
+    if (i < n) put_split(dst, lo, i, src[i]);
 }
 // in-layer taps: fp32 [1024][1536] tap-interleaved in chunks of 16 -> fp16 [1024][1536] tap-interleaved in chunks of 32
 // (the fp16 kernel's K step is 32 halfs = 64-byte LDS rows, like 16 floats)
-__global__ void cvt_taps_kernel(const float* __restrict__ src, _Float16* __restrict__ dst) {
+__global__ void cvt_taps_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, _Float16* __restrict__ lo = nullptr) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)2 * C * KCONV) return;
     const int n = (int)(i / KCONV), r = (int)(i % KCONV);
     const int tap = r / C, c = r % C;
     const int ks = (c / 16) * 48 + tap * 16 + c % 16, kd = (c / 32) * 96 + tap * 32 + c % 32;
-    dst[(long long)n * KCONV + kd] = (_Float16)src[(long long)n * KCONV + ks];
+    put_split(dst, lo, (long long)n * KCONV + kd, src[(long long)n * KCONV + ks]);
 }
 // first layer of a flow: fp32 [1024][3*16] -> fp16 [1024][3*32] (a0p rows are 32 halfs)
-__global__ void cvt_taps0_kernel(const float* __restrict__ src, _Float16* __restrict__ dst) {
+__global__ void cvt_taps0_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, _Float16* __restrict__ lo = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * C * 96) return;
     const int n = i / 96, r = i % 96, tap = r / 32, jj = r % 32;
-    dst[i] = jj < 16 ? (_Float16)src[n * KCONV0 + tap * 16 + jj] : (_Float16)0.f;
+    put_split(dst, lo, i, jj < 16 ? src[n * KCONV0 + tap * 16 + jj] : 0.f);
 }
 // folded conditioning: fp32 [32][1024][4*80] -> fp16 [32][1024][4*96] (each mel frame padded to 96 = 3 K steps)
-__global__ void cvt_cond_kernel(const float* __restrict__ src, _Float16* __restrict__ dst) {
+__global__ void cvt_cond_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, _Float16* __restrict__ lo = nullptr) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)NPH * 2 * C * 384) return;
     const long long row = i / 384;
     const int r = (int)(i % 384), q = r / 96, jj = r % 96;
-    dst[i] = jj < 80 ? (_Float16)src[row * KMEL + q * 80 + jj] : (_Float16)0.f;
+    put_split(dst, lo, i, jj < 80 ? src[row * KMEL + q * 80 + jj] : 0.f);
 }
 
 // audio[m'][0..3] = sigma * z[natural m][0..3]  (z null => zeros); m' = p * PR + f  <->  m = f * 32 + p
@@ -157,7 +164,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <bool HALF>
 __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __restrict__ w,
                                 const float* __restrict__ b, float* __restrict__ x, void* __restrict__ a0p_v,
-                                _Float16* __restrict__ x16, long long M, int h) {
+                                _Float16* __restrict__ x16, long long M, int h, int split = 0) {
+    // split != 0 (split-fp16 mode): the fp16 arrays are [2 planes][M][..]; plane 1 gets v - fp16(v)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of channels
     if (idx >= M * (C / 4)) return;
     const long long m = idx / (C / 4);
@@ -172,6 +180,11 @@ __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __
         if constexpr (HALF) {
             const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             *reinterpret_cast<f16x4*>((_Float16*)a0p_v + m * 32 + c) = hv;
+            if (split) {
+                const f16x4 lv = {(_Float16)(v[0] - (float)hv[0]), (_Float16)(v[1] - (float)hv[1]),
+                                  (_Float16)(v[2] - (float)hv[2]), (_Float16)(v[3] - (float)hv[3])};
+                *reinterpret_cast<f16x4*>((_Float16*)a0p_v + M * 32 + m * 32 + c) = lv;
+            }
         } else {
             const f32x4 fv = {v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>((float*)a0p_v + m * 16 + c) = fv;
@@ -190,6 +203,11 @@ __global__ void wn_start_kernel(const float* __restrict__ audio, const float* __
     if constexpr (HALF) {
         const f16x4 hv = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
         *reinterpret_cast<f16x4*>(x16 + m * C + c) = hv;
+        if (split) {
+            const f16x4 lv = {(_Float16)(acc[0] - (float)hv[0]), (_Float16)(acc[1] - (float)hv[1]),
+                              (_Float16)(acc[2] - (float)hv[2]), (_Float16)(acc[3] - (float)hv[3])};
+            *reinterpret_cast<f16x4*>(x16 + M * C + m * C + c) = lv;
+        }
     }
 }
 
@@ -206,7 +224,9 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const void* __restrict
                                                           const float* __restrict__ inv, float* __restrict__ audio_io,
                                                           float* __restrict__ audio_out, int out_natural,
                                                           const float* __restrict__ z, int zoff, int n_early,
-                                                          float sigma, long long M, int h, int PR, int BT) {
+                                                          float sigma, long long M, int h, int PR, int BT,
+                                                          long long lo_plane = 0) {
+    // lo_plane != 0 (split-fp16 mode): activation = hi + lo, lo at + lo_plane halfs
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long m0 = wave * RPW;
@@ -232,6 +252,12 @@ __global__ __launch_bounds__(256) void wn_end_fold_kernel(const void* __restrict
                 const f16x4 h1 = *reinterpret_cast<const f16x4*>(al + C / 2);
                 a0[r] = f32x4{(float)h0[0], (float)h0[1], (float)h0[2], (float)h0[3]};
                 a1[r] = f32x4{(float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]};
+                if (lo_plane) {
+                    const f16x4 l0 = *reinterpret_cast<const f16x4*>(al + lo_plane);
+                    const f16x4 l1 = *reinterpret_cast<const f16x4*>(al + lo_plane + C / 2);
+                    a0[r] += f32x4{(float)l0[0], (float)l0[1], (float)l0[2], (float)l0[3]};
+                    a1[r] += f32x4{(float)l1[0], (float)l1[1], (float)l1[2], (float)l1[3]};
+                }
             } else {
                 const float* al = (const float*)acts_v + layer * layer_stride + lane * 4;
                 a0[r] = *reinterpret_cast<const f32x4*>(al + m * C);
@@ -321,6 +347,7 @@ void waveglow_free(tts_hip_engine* e) {
     e->wg.a0p16.release();
     e->wg.mel16.release();
     e->wg.f16_ready = false;
+    e->wg.x3_ready = false;
     e->wg.io_mel.release();
     e->wg.io_z.release();
     e->wg.io_out.release();
@@ -588,14 +615,68 @@ static int waveglow_build_f16(tts_hip_engine* e) {
     return TTS_HIP_OK;
 }
 
+// Split-fp16 operands ([2 planes] per matrix: hi = fp16(w), lo = fp16(w - hi)), built once from the packed fp32 copies.
+static int waveglow_build_x3(tts_hip_engine* e) {
+    WaveGlowDev& wg = e->wg;
+    if (wg.x3_ready) return TTS_HIP_OK;
+    hipStream_t st = e->stream;
+    auto alloc_h = [&](size_t n, _Float16** out) -> int {
+        void* p = nullptr;
+        HIPCHK(e, hipMalloc(&p, n * sizeof(_Float16)));
+        wg.allocs.push_back(p);
+        *out = (_Float16*)p;
+        return TTS_HIP_OK;
+    };
+    int rc;
+    for (int k = 0; k < 12; ++k)
+        for (int i = 0; i < 8; ++i) {
+            WgLayerDev& ly = wg.flow[k].layer[i];
+            _Float16 *a, *c, *r = nullptr;
+            if (i == 0) {
+                const size_t n = (size_t)2 * C * 96;
+                if ((rc = alloc_h(2 * n, &a))) return rc;
+                hipLaunchKernelGGL(cvt_taps0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.in_Bt, a, a + n);
+            } else {
+                const size_t n = (size_t)2 * C * KCONV;
+                if ((rc = alloc_h(2 * n, &a))) return rc;
+                hipLaunchKernelGGL(cvt_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.in_Bt, a, a + n);
+            }
+            {
+                const size_t n = (size_t)NPH * 2 * C * 384;
+                if ((rc = alloc_h(2 * n, &c))) return rc;
+                hipLaunchKernelGGL(cvt_cond_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.cond_Bt, c, c + n);
+            }
+            if (ly.rs_n) {
+                const size_t n = (size_t)C * C;
+                if ((rc = alloc_h(2 * n, &r))) return rc;
+                hipLaunchKernelGGL(cvt_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.rs_Bt, r,
+                                   (long long)n, r + n);
+            }
+            HIPCHK(e, hipGetLastError());
+            ly.in_Bt_x3 = a;
+            ly.cond_Bt_x3 = c;
+            ly.rs_Bt_x3 = r;
+        }
+    HIPCHK(e, hipStreamSynchronize(st));
+    wg.x3_ready = true;
+    return TTS_HIP_OK;
+}
+
 // precision 0: exact fp32 MFMA path.  precision 1: fp16 operands (activations, mel and weights fp16 in HBM), fp32
-// accumulation and fp32 epilogue math, fp32 master copy of the residual stream and of the flow state.
+// accumulation and fp32 epilogue math, fp32 master copy of the residual stream and of the flow state.  precision 2: split
+// fp16 -- every GEMM operand is a pair of fp16 planes (hi, lo), three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32
+// accumulation: ~22 operand bits, i.e. fp32-class results at 3/16 of the fp32 MFMA cost.
 int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const float* d_z, float sigma, float* d_audio,
                  int precision) {
     WaveGlowDev& wg = e->wg;
     const bool half = precision == 1;
+    const bool x3 = precision == 2;
     if (half) {
         int rc = waveglow_build_f16(e);
+        if (rc) return rc;
+    }
+    if (x3) {
+        int rc = waveglow_build_x3(e);
         if (rc) return rc;
     }
     const int BT = B * T;                                        // frames
@@ -604,9 +685,11 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     const bool tile128 = pr128 * 1.05 < pr256;
     // short utterances (a sentence at batch 1): 64-row tiles when they save padding
     const int pr_big = tile128 ? pr128 : pr256;
-    const bool row64 = BT <= 512 && getenv("TTS_HIP_NO_ROW64") == nullptr &&
-                       (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
-    const int PR = row64 ? pr64 : tile128 ? pr128 : pr256;
+    const bool row64 = x3 ? pr64 * 1.15 < pr256      // split fp16 has two tile shapes: 64 x 128 and 256 x 128
+                          : BT <= 512 && getenv("TTS_HIP_NO_ROW64") == nullptr &&
+                            (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
+    const int PR = row64 ? pr64 : (tile128 && !x3) ? pr128 : pr256;
+    const int NP = x3 ? 2 : 1;                                   // fp16 planes per operand
     const long long M = (long long)NPH * PR;                     // phase-major rows (incl. padding)
     // 128 x 128 tiles would leave block slots (3 per CU) empty -> 128 x 64 tiles, twice the blocks
     const bool tile64 = !row64 && tile128 && (M / 128) * 8 < 768;
@@ -614,11 +697,11 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         return set_err(e, TTS_HIP_EINVAL, "waveglow_infer: B*T = %d frames exceeds one call's limit (~32000)", BT);
     HIPCHK(e, wg.x.ensure((size_t)M * C * 4));
     HIPCHK(e, wg.audio.ensure((size_t)M * 8 * 4));
-    if (half) {
-        HIPCHK(e, wg.x16.ensure((size_t)M * C * 2));
-        HIPCHK(e, wg.acts16.ensure((size_t)8 * M * C * 2));
-        HIPCHK(e, wg.a0p16.ensure((size_t)M * 32 * 2));
-        HIPCHK(e, wg.mel16.ensure((size_t)BT * 80 * 2 + 256));
+    if (half || x3) {
+        HIPCHK(e, wg.x16.ensure((size_t)NP * M * C * 2));
+        HIPCHK(e, wg.acts16.ensure((size_t)8 * NP * M * C * 2));
+        HIPCHK(e, wg.a0p16.ensure((size_t)NP * M * 32 * 2));
+        HIPCHK(e, wg.mel16.ensure((size_t)NP * BT * 80 * 2 + 256));
     } else {
         HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));      // activations of the 8 layers of one flow
         HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
@@ -630,9 +713,10 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
 
     const unsigned mb = (unsigned)((M + 255) / 256);
     hipLaunchKernelGGL(init_audio_kernel, dim3(mb), dim3(256), 0, st, d_z, sigma, wg.audio.f(), PR, BT);
-    if (half) {
+    if (half || x3) {
         const long long n = (long long)BT * 80;
-        hipLaunchKernelGGL(cvt_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mel, mel16, n);
+        hipLaunchKernelGGL(cvt_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mel, mel16, n,
+                           x3 ? mel16 + n : (_Float16*)nullptr);
     }
     HIPCHK(e, hipGetLastError());
 
@@ -643,9 +727,9 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         {
             const long long n4 = M * (C / 4);
             const dim3 grid((unsigned)((n4 + 255) / 256));
-            if (half)
+            if (half || x3)
                 hipLaunchKernelGGL(wn_start_kernel<true>, grid, dim3(256), 0, st, wg.audio.f(), fl.start_w, fl.start_b,
-                                   wg.x.f(), wg.a0p16.p, x16, M, h);
+                                   wg.x.f(), wg.a0p16.p, x16, M, h, x3 ? 1 : 0);
             else
                 hipLaunchKernelGGL(wn_start_kernel<false>, grid, dim3(256), 0, st, wg.audio.f(), fl.start_w, fl.start_b,
                                    wg.x.f(), wg.a0p.p, (_Float16*)nullptr, M, h);
@@ -664,7 +748,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.bias = ly.in_bias;
             g.mode = EPI_GATE;
             g.split = 2 * C;
-            if (!half) {
+            if (!half && !x3) {
                 if (i == 0) {
                     // first layer: conv(start(a0)) composed at load time -> K = 3 taps x 16 (h + 1 used) instead of 3 x 512
                     for (int tap = 0; tap < 3; ++tap) g.seg[tap] = ASeg{wg.a0p.f(), 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP};
@@ -707,28 +791,36 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     timing_end(e);
                 }
             } else {
-                // fp16 operands, described in float units (one unit = 2 halfs): ld / k / kpad / ldb are halved
+                // fp16 operands, described in float units (one unit = 2 halfs): ld / k / kpad / ldb are halved.  Split mode:
+                // every operand has a second plane (the lo halves) at a fixed offset, loaded next to the first one.
+                const long long plX = x3 ? (long long)M * C / 2 : 0, plA0 = x3 ? (long long)M * 16 : 0,
+                                plMel = x3 ? (long long)BT * 40 : 0;
                 if (i == 0) {
                     for (int tap = 0; tap < 3; ++tap)
-                        g.seg[tap] = ASeg{(const float*)wg.a0p16.p, 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP};
+                        g.seg[tap] = ASeg{(const float*)wg.a0p16.p, 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP, plA0};
                     g.ldb = 96 / 2;
+                    g.planeB = x3 ? (long long)2 * C * 96 / 2 : 0;
                 } else {
                     for (int tap = 0; tap < 3; ++tap)
-                        g.seg[tap] = ASeg{(const float*)x16, C / 2, (tap - 1) * d, C / 2, C / 2, SEG_PHASE_TAP};
+                        g.seg[tap] = ASeg{(const float*)x16, C / 2, (tap - 1) * d, C / 2, C / 2, SEG_PHASE_TAP, plX};
                     g.ldb = KCONV / 2;
+                    g.planeB = x3 ? (long long)2 * C * KCONV / 2 : 0;
                 }
-                for (int q = 0; q < 4; ++q) g.seg[3 + q] = ASeg{(const float*)mel16, 40, -q, 40, 48, SEG_FRAME};
-                g.Bt = (const float*)ly.in_Bt16;
-                g.Bt2 = (const float*)ly.cond_Bt16;
+                for (int q = 0; q < 4; ++q) g.seg[3 + q] = ASeg{(const float*)mel16, 40, -q, 40, 48, SEG_FRAME, plMel};
+                g.Bt = (const float*)(x3 ? ly.in_Bt_x3 : ly.in_Bt16);
+                g.Bt2 = (const float*)(x3 ? ly.cond_Bt_x3 : ly.cond_Bt16);
                 g.ldb2 = 384 / 2;
                 g.strideB2p = (long long)2 * C * 384 / 2;
-                _Float16* acts_i = acts16 + (size_t)i * M * C;
+                g.planeB2 = x3 ? (long long)NPH * 2 * C * 384 / 2 : 0;
+                _Float16* acts_i = acts16 + (size_t)i * NP * M * C;
                 g.out0 = wg.x.f();           // unused by the gate epilogue (fp16 output below)
                 g.ld0 = C;
                 g.out0h = acts_i;
                 g.ld0h = C;
+                g.planeOut = (long long)M * C;
                 timing_begin(e, i == 0 ? 3 : 0);
-                if (row64) HIPCHK(e, i == 0 ? gemm_wn_in0_r64h(g, st) : gemm_wn_in_r64h(g, st));
+                if (x3) HIPCHK(e, i == 0 ? gemm_wn_in0_x3(g, row64, st) : gemm_wn_in_x3(g, row64, st));
+                else if (row64) HIPCHK(e, i == 0 ? gemm_wn_in0_r64h(g, st) : gemm_wn_in_r64h(g, st));
                 else if (tile64) HIPCHK(e, i == 0 ? gemm_wn_in0_64h(g, st) : gemm_wn_in_64h(g, st));
                 else HIPCHK(e, i == 0 ? gemm_wn_in0_h(g, tile128, st) : gemm_wn_in_h(g, tile128, st));
                 timing_end(e);
@@ -738,9 +830,10 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.N = C;
                     r.L = (int)M;
                     r.nseg = 1;
-                    r.seg[0] = ASeg{(const float*)acts_i, C / 2, 0, C / 2, C / 2};
-                    r.Bt = (const float*)ly.rs_Bt16;
+                    r.seg[0] = ASeg{(const float*)acts_i, C / 2, 0, C / 2, C / 2, SEG_ROWS, plX};
+                    r.Bt = (const float*)(x3 ? ly.rs_Bt_x3 : ly.rs_Bt16);
                     r.ldb = C / 2;
+                    r.planeB = x3 ? (long long)C * C / 2 : 0;
                     r.bias = ly.rs_bias;
                     r.mode = EPI_LINEAR;
                     r.act = ACT_NONE;
@@ -750,8 +843,10 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.acc0 = 1;
                     r.out0h = x16;           // fp16 shadow = operand of the next layer's taps
                     r.ld0h = C;
+                    r.planeOut = (long long)M * C;
                     timing_begin(e, 1);
-                    HIPCHK(e, row64 ? gemm_wn_res_r64h(r, st) : tile64 ? gemm_wn_res_64h(r, st) : gemm_wn_res_h(r, st));
+                    if (x3) HIPCHK(e, gemm_wn_res_x3(r, row64, st));
+                    else HIPCHK(e, row64 ? gemm_wn_res_r64h(r, st) : tile64 ? gemm_wn_res_64h(r, st) : gemm_wn_res_h(r, st));
                     timing_end(e);
                 }
             }
@@ -760,10 +855,10 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         float* dst = (k == 0) ? d_audio : wg.audio.f();
         const long long waves = (M + RPW - 1) / RPW;
         const dim3 grid((unsigned)((waves + 3) / 4));
-        if (half)
-            hipLaunchKernelGGL(wn_end_fold_kernel<true>, grid, dim3(256), 0, st, (const void*)acts16, (long long)M * C,
-                               fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, k == 0 ? 1 : 0, d_z, zoff, early ? 2 : 0,
-                               sigma, M, h, PR, BT);
+        if (half || x3)
+            hipLaunchKernelGGL(wn_end_fold_kernel<true>, grid, dim3(256), 0, st, (const void*)acts16,
+                               (long long)NP * M * C, fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, k == 0 ? 1 : 0, d_z,
+                               zoff, early ? 2 : 0, sigma, M, h, PR, BT, x3 ? (long long)M * C : 0ll);
         else
             hipLaunchKernelGGL(wn_end_fold_kernel<false>, grid, dim3(256), 0, st, (const void*)wg.acts.p,
                                (long long)M * C, fl.end_w, fl.end_b, fl.inv, wg.audio.f(), dst, k == 0 ? 1 : 0, d_z,

@@ -77,8 +77,8 @@ class HipRuntime(Runtime):
         self._rng = np.random.default_rng(seed)
         self.max_decoder_steps = int(kwargs.get('max_decoder_steps', 2000))
         self.vocoder_precision = kwargs.get('vocoder_precision', 'f32')
-        if self.vocoder_precision not in ('f32', 'f16'):
-            raise ValueError(f"vocoder_precision must be 'f32' or 'f16', got {self.vocoder_precision!r}")
+        if self.vocoder_precision not in ('f32', 'f16', 'f16x3'):
+            raise ValueError(f"vocoder_precision must be 'f32', 'f16x3' or 'f16', got {self.vocoder_precision!r}")
         self.synthesizer_precision = kwargs.get('synthesizer_precision', 'f32')
         if self.synthesizer_precision not in ('f32', 'f16'):
             raise ValueError(f"synthesizer_precision must be 'f32' or 'f16', got {self.synthesizer_precision!r}")
