@@ -172,6 +172,9 @@ def main():
     ap.add_argument('--cpu-frames', type=int, default=480, help='mel frames of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary (untimed-region) metrics')
+    ap.add_argument('--precision', default='f32', choices=('f32', 'f16x3', 'f16'),
+                    help="arithmetic of the timed path: f32 = exact fp32 MFMA (default, the contract's config); "
+                         "f16x3 = split fp16, fp32-class accuracy; f16 = fp16 operands")
     args = ap.parse_args()
 
     import torch
@@ -213,13 +216,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        eng.waveglow_infer(mel, z=z, sigma=1.0)
+        eng.waveglow_infer(mel, z=z, sigma=1.0, precision=args.precision)
     if not args.no_kernel_timing:
         eng.kernel_timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = eng.waveglow_infer(mel, z=z, sigma=1.0)       # returns after the engine stream has drained
+        out = eng.waveglow_infer(mel, z=z, sigma=1.0, precision=args.precision)   # returns after the engine stream has drained
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
@@ -236,7 +239,15 @@ def main():
     if rank == 0:
         M = B * T * 32
         roofline = None
-        if launches:
+        if launches and args.precision != 'f32':
+            # fp16 matrix pipe (2.5 PFLOP/s dense): the split mode issues three MFMAs per product
+            mfma_flops = wn_in_layer_flops(M) * (3 if args.precision == 'f16x3' else 1)
+            achieved = mfma_flops / (avg_us * 1e-6) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': achieved / 2500.0,
+                        'flops_per_launch': mfma_flops, 'traffic': None, 'launches_timed': launches,
+                        'avg_launch_us': avg_us,
+                        'kernel': 'WN in-layer implicit GEMM, fp16 MFMA (' + args.precision + ')'}
+        elif launches:
             achieved = wn_in_layer_flops(M) / (avg_us * 1e-6) / 1e12
             roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -252,10 +263,11 @@ def main():
             threads = min(os.cpu_count() or 1, 16)
             cpu = cpu_baseline(w, cfg, args.cpu_frames, threads)
         result = {
-            'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)',
+            'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)' if args.precision == 'f32' else
+                      f'audio samples/sec (22.05 kHz WaveGlow vocoding, {args.precision})',
             'value': samples / dt, 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'WaveGlow-only vocoding of precomputed 80x{T} mel, batch {B} per GPU, fp32 '
                                    f'(BASELINE.json configs[1])', 'batch_per_gpu': B, 'mel_frames': T,
                        'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
