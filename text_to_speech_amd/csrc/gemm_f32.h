@@ -73,6 +73,9 @@ struct GemmArgs {
     _Float16* out0h; long long ld0h;          // HALF kernels: fp16 output (gate) / fp16 shadow of out0 (linear); may be null
     long long planeB, planeB2;                // PL == 2 kernels: second-plane offsets (in floats) of Bt and Bt2
     long long planeOut;                       // PL == 2 kernels: second-plane offset (in halfs) of out0h
+    int wide_epi;                             // LDS-DMA kernels, EPI_LINEAR, single output, no row mask, M % 32 == 0 and
+                                              // N % 32 == 0: transpose each 32 x 32 accumulator tile through LDS and use
+                                              // 16-byte loads / stores for out0 (incl. its read-modify-write) and out0h
     float* out1; long long ld1; int acc1;
     long long strideOutZ;
     const uint8_t* rowmask;         // optional [M]: rows with mask 0 produce act(altbias[n]) instead
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         float bv[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) bv[j] = (bias && cbase + j * 32 < g.N) ? bias[cbase + j * 32] : 0.f;
-        const bool rmw = g.mode == EPI_LINEAR && (second ? g.acc1 : g.acc0);
+        const bool rmw = g.mode == EPI_LINEAR && (second ? g.acc1 : g.acc0) && !(DMA && g.wide_epi);
         if (rmw) {
             // branch-free batch of dword buffer loads (rows >= M and columns >= N read as 0), one wait for all
             const __amdgpu_buffer_rsrc_t rsO = make_rsrc(outp + (long long)(m0 + wr * RT * 32) * ldo);
@@ -557,6 +560,58 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             return;
         }
     }
+    if constexpr (DMA) {
+        if (g.wide_epi) {
+            // The C/D layout of the 32 x 32 MFMA gives a lane one column and 16 scattered rows: stored directly that is
+            // 16 dword stores (+ 16 loads for a read-modify-write, + 2-byte stores for fp16 shadows) per tile.  The pipeline
+            // buffers are free now, so each wave transposes its tiles one at a time through a private 32 x 36 float patch of
+            // LDS: afterwards lane l holds 4 consecutive columns of row (l / 8) + 8 pass, i.e. 16-byte accesses, 8 lanes per
+            // 128-byte row segment.  (Residual GEMM of the split-fp16 mode: 0.61 -> see DESIGN.)
+            __builtin_amdgcn_s_barrier();                         // every wave is done reading the last tile
+            float* patch = smem + wave * (32 * 36);
+            const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+            const bool accum = second ? g.acc1 : g.acc0;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int mrow0 = m0 + wr * RT * 32 + i * 32;
+                    const int ncol = ncol0 - li + j * 32 + pc4;  // first of this lane's 4 output columns
+                    f32x4 oldv[4];
+                    if (accum) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            oldv[q] = *reinterpret_cast<const f32x4*>(outp + (long long)(mrow0 + prow + 8 * q) * ldo + ncol);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private patch: no barrier needed
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(patch + (prow + 8 * q) * 36 + pc4);
+                        if (accum) v += oldv[q];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], g.act);
+                        const long long mrow = mrow0 + prow + 8 * q;
+                        *reinterpret_cast<f32x4*>(outp + mrow * ldo + ncol) = v;
+                        if constexpr (HALF) {
+                            if (g.out0h && !second) {
+                                typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+                                const f16x4e hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                                *reinterpret_cast<f16x4e*>(g.out0h + mrow * g.ld0h + ncol) = hv;
+                                if constexpr (PL == 2) {
+                                    const f16x4e lv = {(_Float16)(v[0] - (float)hv[0]), (_Float16)(v[1] - (float)hv[1]),
+                                                       (_Float16)(v[2] - (float)hv[2]), (_Float16)(v[3] - (float)hv[3])};
+                                    *reinterpret_cast<f16x4e*>(g.out0h + g.planeOut + mrow * g.ld0h + ncol) = lv;
+                                }
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next tile overwrites it
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -604,6 +659,11 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
         // tiles must not straddle phases; the interleaved-tap descriptor spans at most the whole operand (31-bit offsets)
         if (g.phase_rows % BM != 0 || g.M != 32 * g.phase_rows) return hipErrorInvalidValue;
         if (32.0 * g.phase_rows * (double)g.seg[0].ld * 4.0 >= 2147483648.0 - 65536.0) return hipErrorInvalidValue;
+    }
+    if (g.wide_epi) {
+        if (PIPE != PIPE_DMA || g.mode != EPI_LINEAR || g.rowmask || g.M % BM != 0 || g.N % BN != 0 || g.ld0 % 4 != 0 ||
+            (g.split < g.N && g.ld1 % 4 != 0) || (size_t)(WR * WC) * 32 * 36 * sizeof(float) > lds)
+            return hipErrorInvalidValue;
     }
     if (NI > 0) {
         if (g.nseg < NI) return hipErrorInvalidValue;

@@ -825,6 +825,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.out0 = wg.x.f();
                     r.ld0 = C;
                     r.acc0 = 1;
+                    r.wide_epi = 1;
                     timing_begin(e, 1);
                     HIPCHK(e, row64 ? gemm_wn_res_r64(r, st) : tile64 ? gemm_wn_res_64(r, st) : gemm_wn_res_skip(r, st));
                     timing_end(e);
@@ -883,6 +884,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     r.out0h = x16;           // fp16 shadow = operand of the next layer's taps
                     r.ld0h = C;
                     r.planeOut = (long long)M * C;
+                    r.wide_epi = 1;
                     timing_begin(e, 1);
                     if (x3) HIPCHK(e, gemm_wn_res_x3(r, row64, st));
                     else HIPCHK(e, row64 ? gemm_wn_res_r64h(r, st) : tile64 ? gemm_wn_res_64h(r, st) : gemm_wn_res_h(r, st));
