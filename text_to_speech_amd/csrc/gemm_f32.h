@@ -537,6 +537,46 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             // sigmoid pre-activations, so MFMA column tiles (2q, 2q + 1) of a wave pair up; output channel =
             // (first column of the pair / 64) * 32 + lane column.
             float* out = outp;
+            if constexpr (DMA) {
+                if (g.wide_epi) {
+                    // same LDS transpose as the linear epilogue below: the 32 x 32 gated tile of a (tanh, sigmoid) pair
+                    // leaves as 16-byte (fp32) / 8-byte (fp16 planes) stores, 8 lanes per row segment
+                    __builtin_amdgcn_s_barrier();
+                    float* patch = smem + wave * (32 * 36);
+                    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+#pragma unroll
+                    for (int i = 0; i < RT; ++i)
+#pragma unroll
+                        for (int q = 0; q < CT / 2; ++q) {
+                            const int ch4 = ((n0 + wc * CT * 32) / 64 + q) * 32 + pc4;
+                            const int mrow0 = m0 + wr * RT * 32 + i * 32;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] =
+                                    gate_tanh_sigmoid(acc[i][2 * q][r], acc[i][2 * q + 1][r]);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(patch + (prow + 8 * qq) * 36 + pc4);
+                                const long long mrow = mrow0 + prow + 8 * qq;
+                                if constexpr (HALF) {
+                                    typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+                                    const f16x4e hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                                    *reinterpret_cast<f16x4e*>(g.out0h + mrow * g.ld0h + ch4) = hv;
+                                    if constexpr (PL == 2) {
+                                        const f16x4e lv = {(_Float16)(v[0] - (float)hv[0]), (_Float16)(v[1] - (float)hv[1]),
+                                                           (_Float16)(v[2] - (float)hv[2]), (_Float16)(v[3] - (float)hv[3])};
+                                        *reinterpret_cast<f16x4e*>(g.out0h + g.planeOut + mrow * g.ld0h + ch4) = lv;
+                                    }
+                                } else {
+                                    *reinterpret_cast<f32x4*>(out + mrow * g.ld0 + ch4) = v;
+                                }
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                    return;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -661,7 +701,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
         if (32.0 * g.phase_rows * (double)g.seg[0].ld * 4.0 >= 2147483648.0 - 65536.0) return hipErrorInvalidValue;
     }
     if (g.wide_epi) {
-        if (PIPE != PIPE_DMA || g.mode != EPI_LINEAR || g.rowmask || g.M % BM != 0 || g.N % BN != 0 || g.ld0 % 4 != 0 ||
+        if (PIPE != PIPE_DMA || g.rowmask || g.M % BM != 0 || g.N % BN != 0 || g.ld0 % 4 != 0 ||
             (g.split < g.N && g.ld1 % 4 != 0) || (size_t)(WR * WC) * 32 * 36 * sizeof(float) > lds)
             return hipErrorInvalidValue;
     }

@@ -787,6 +787,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.bias = ly.in_bias;
             g.mode = EPI_GATE;
             g.split = 2 * C;
+            g.wide_epi = 1;
             if (!half && !x3) {
                 if (i == 0) {
                     // first layer: conv(start(a0)) composed at load time -> K = 3 taps x 16 (h + 1 used) instead of 3 x 512
