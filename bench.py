@@ -233,7 +233,8 @@ def main():
 
     avg_us, launches = (0.0, 0) if args.no_kernel_timing else eng.kernel_time_us(KERNEL_WN_IN)
     eng.kernel_timing(False)
-    extra = secondary_metrics(eng, dev, rank) if (rank == 0 and not args.no_extra) else None
+    # secondary metrics and the CPU leg only at N = 1 (the other ranks would idle at the final barrier)
+    extra = secondary_metrics(eng, dev, rank) if (rank == 0 and world == 1 and not args.no_extra) else None
     samples = world * B * T * 256 * args.steps
     result = None
     if rank == 0:
@@ -259,7 +260,7 @@ def main():
                         'kernel': 'gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; K = 1536 taps + 320 folded conditioning)', 'launches_timed': launches,
                         'avg_launch_us': avg_us}
         cpu = None
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:
             threads = min(os.cpu_count() or 1, 16)
             cpu = cpu_baseline(w, cfg, args.cpu_frames, threads)
         result = {
