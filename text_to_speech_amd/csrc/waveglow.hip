@@ -131,13 +131,17 @@ __global__ void cvt_taps0_kernel(const float* __restrict__ src, _Float16* __rest
     const int n = i / 96, r = i % 96, tap = r / 32, jj = r % 32;
     put_split(dst, lo, i, jj < 16 ? src[n * KCONV0 + tap * 16 + jj] : 0.f);
 }
-// folded conditioning: fp32 [32][1024][4*80] -> fp16 [32][1024][4*96] (each mel frame padded to 96 = 3 K steps)
-__global__ void cvt_cond_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, _Float16* __restrict__ lo = nullptr) {
+
+// fp16 modes: the conditioning operand of frame f is the contiguous window [mel_t | mel_{t-1} | mel_{t-2} | mel_{t-3}]
+// (320 halfs = 10 K steps; four separate 80-wide segments would each be padded to 96 = 12 steps), zeros before the start
+// of the utterance.  `lo` (may be null) receives the second plane of the split mode.
+__global__ void mel_window_kernel(const float* __restrict__ mel, _Float16* __restrict__ dst, _Float16* __restrict__ lo,
+                                  int BT, int T) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)NPH * 2 * C * 384) return;
-    const long long row = i / 384;
-    const int r = (int)(i % 384), q = r / 96, jj = r % 96;
-    put_split(dst, lo, i, jj < 80 ? src[row * KMEL + q * 80 + jj] : 0.f);
+    if (i >= (long long)BT * KMEL) return;
+    const int f = (int)(i / KMEL), r = (int)(i % KMEL), q = r / 80, j = r % 80;
+    const int t = f % T;
+    put_split(dst, lo, i, t - q >= 0 ? mel[(long long)(f - q) * 80 + j] : 0.f);
 }
 
 // audio[m'][0..3] = sigma * z[natural m][0..3]  (z null => zeros); m' = p * PR + f  <->  m = f * 32 + p
@@ -635,10 +639,11 @@ static int waveglow_build_f16(tts_hip_engine* e) {
                 const long long n = (long long)2 * C * KCONV;
                 hipLaunchKernelGGL(cvt_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.in_Bt, a);
             }
-            if ((rc = alloc_h((size_t)NPH * 2 * C * 384, &c))) return rc;
+            if ((rc = alloc_h((size_t)NPH * 2 * C * KMEL, &c))) return rc;
             {
-                const long long n = (long long)NPH * 2 * C * 384;
-                hipLaunchKernelGGL(cvt_cond_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.cond_Bt, c);
+                const long long n = (long long)NPH * 2 * C * KMEL;
+                hipLaunchKernelGGL(cvt_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.cond_Bt, c, n,
+                                   (_Float16*)nullptr);
             }
             if (ly.rs_n) {
                 if ((rc = alloc_h((size_t)C * C, &r))) return rc;
@@ -681,9 +686,10 @@ static int waveglow_build_x3(tts_hip_engine* e) {
                 hipLaunchKernelGGL(cvt_taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.in_Bt, a, a + n);
             }
             {
-                const size_t n = (size_t)NPH * 2 * C * 384;
+                const size_t n = (size_t)NPH * 2 * C * KMEL;
                 if ((rc = alloc_h(2 * n, &c))) return rc;
-                hipLaunchKernelGGL(cvt_cond_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.cond_Bt, c, c + n);
+                hipLaunchKernelGGL(cvt_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ly.cond_Bt, c,
+                                   (long long)n, c + n);
             }
             if (ly.rs_n) {
                 const size_t n = (size_t)C * C;
@@ -740,7 +746,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         HIPCHK(e, wg.x16.ensure((size_t)NP * M * C * 2));
         HIPCHK(e, wg.acts16.ensure((size_t)8 * NP * M * C * 2));
         HIPCHK(e, wg.a0p16.ensure((size_t)NP * M * 32 * 2));
-        HIPCHK(e, wg.mel16.ensure((size_t)NP * BT * 80 * 2 + 256));
+        HIPCHK(e, wg.mel16.ensure((size_t)NP * BT * KMEL * 2 + 256));
     } else {
         HIPCHK(e, wg.acts.ensure((size_t)8 * M * C * 4));      // activations of the 8 layers of one flow
         HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
@@ -753,9 +759,9 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     const unsigned mb = (unsigned)((M + 255) / 256);
     hipLaunchKernelGGL(init_audio_kernel, dim3(mb), dim3(256), 0, st, d_z, sigma, wg.audio.f(), PR, BT);
     if (half || x3) {
-        const long long n = (long long)BT * 80;
-        hipLaunchKernelGGL(cvt_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mel, mel16, n,
-                           x3 ? mel16 + n : (_Float16*)nullptr);
+        const long long n = (long long)BT * KMEL;
+        hipLaunchKernelGGL(mel_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mel, mel16,
+                           x3 ? mel16 + n : (_Float16*)nullptr, BT, T);
     }
     HIPCHK(e, hipGetLastError());
 
@@ -835,7 +841,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 // fp16 operands, described in float units (one unit = 2 halfs): ld / k / kpad / ldb are halved.  Split mode:
                 // every operand has a second plane (the lo halves) at a fixed offset, loaded next to the first one.
                 const long long plX = x3 ? (long long)M * C / 2 : 0, plA0 = x3 ? (long long)M * 16 : 0,
-                                plMel = x3 ? (long long)BT * 40 : 0;
+                                plMel = x3 ? (long long)BT * KMEL / 2 : 0;
+                g.nseg = 4;                  // 3 taps + one contiguous 4-frame mel window
                 if (i == 0) {
                     for (int tap = 0; tap < 3; ++tap)
                         g.seg[tap] = ASeg{(const float*)wg.a0p16.p, 16, (tap - 1) * d, 16, 16, SEG_PHASE_TAP, plA0};
@@ -847,12 +854,12 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     g.ldb = KCONV / 2;
                     g.planeB = x3 ? (long long)2 * C * KCONV / 2 : 0;
                 }
-                for (int q = 0; q < 4; ++q) g.seg[3 + q] = ASeg{(const float*)mel16, 40, -q, 40, 48, SEG_FRAME, plMel};
+                g.seg[3] = ASeg{(const float*)mel16, KMEL / 2, 0, KMEL / 2, KMEL / 2, SEG_FRAME, plMel};
                 g.Bt = (const float*)(x3 ? ly.in_Bt_x3 : ly.in_Bt16);
                 g.Bt2 = (const float*)(x3 ? ly.cond_Bt_x3 : ly.cond_Bt16);
-                g.ldb2 = 384 / 2;
-                g.strideB2p = (long long)2 * C * 384 / 2;
-                g.planeB2 = x3 ? (long long)NPH * 2 * C * 384 / 2 : 0;
+                g.ldb2 = KMEL / 2;
+                g.strideB2p = (long long)2 * C * KMEL / 2;
+                g.planeB2 = x3 ? (long long)NPH * 2 * C * KMEL / 2 : 0;
                 _Float16* acts_i = acts16 + (size_t)i * NP * M * C;
                 g.out0 = wg.x.f();           // unused by the gate epilogue (fp16 output below)
                 g.ld0 = C;
