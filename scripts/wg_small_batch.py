@@ -9,7 +9,7 @@ e = HipEngine(0)
 e.load_state(weights.synth_waveglow(config.WaveGlowConfig()))
 e.finalize()
 for prec in ('f32', 'f16x3', 'f16'):
-    for B, T in [(1, 50), (1, 100), (1, 170), (1, 200), (1, 300), (1, 400), (1, 800)]:
+    for B, T in [(1, 50), (1, 100), (1, 170), (1, 200), (1, 300), (1, 400), (1, 600), (1, 800)]:
         mel = torch.rand((B, T, 80), device='cuda') * 12.7 - 11.5
         z = torch.randn((B, T * 32, 8), device='cuda')
         for _ in range(2):
