@@ -18,7 +18,7 @@ e1, e2 = HipEngine(0), HipEngine(0)
 tw, ww = weights.synth_tacotron2(Tacotron2Config(), seed=1234), weights.synth_waveglow(WaveGlowConfig())
 for e in (e1, e2):
     e.load_state(tw); e.load_state(ww); e.finalize()
-model = Tacotron2(HipRuntime('t', model='tacotron2', engine=e1, seed=0, synthesizer_precision=prec))
+model = Tacotron2(HipRuntime('t', model='tacotron2', engine=e1, seed=0, synthesizer_precision='f16' if prec == 'f16' else 'f32'))
 voc_same = WaveGlow(HipRuntime('w', model='waveglow', engine=e1, seed=0, vocoder_precision=prec))
 voc_own = WaveGlow(HipRuntime('w2', model='waveglow', engine=e2, seed=0, vocoder_precision=prec))
 rng = np.random.default_rng(0)
