@@ -769,17 +769,19 @@ inline hipError_t gemm_wn_in_x3(const GemmArgs& g, bool small, hipStream_t s) {
                  : launch_gemm<4, 2, 2, 4, TTS_WN_BK, 1, TAG_WN_IN, WN_TAPS, PIPE_DMA, true, 2, 2>(g, 1, s);
 }
 #ifndef TTS_X3_VAR
-#define TTS_X3_VAR 1   // bit 0: 256 x 256 tiles for the first layer of a flow (613 vs 690 us); bit 1: for the residual GEMM (651 vs 616 us: off)
+#define TTS_X3_VAR 1   // bit 0: 256 x 256 tiles for the first layer of a flow (613 vs 690 us)
 #endif
 inline hipError_t gemm_wn_in0_x3(const GemmArgs& g, bool small, hipStream_t s) {
     if (!small && (TTS_X3_VAR & 1)) return launch_gemm<4, 2, 2, 4, TTS_WN_BK, 1, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true, 2, 2>(g, 1, s);
     return small ? launch_gemm<2, 2, 1, 2, TTS_WN_BK, 2, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true, 3, 2>(g, 1, s)
                  : launch_gemm<4, 2, 2, 2, TTS_WN_BK, 1, TAG_WN_IN0, WN_TAPS, PIPE_DMA, true, 3, 2>(g, 1, s);
 }
+// residual GEMM (K = 512: short main loop, heavy read-modify-write epilogue): 128 x 128 tiles, 4 waves, two LDS buffers =
+// 64 KB, so two blocks share a CU and one block's epilogue overlaps the other's loop (494 us; 540-570 us with one
+// 256 x 128 block per CU, 584 us with 64 x 128 tiles)
 inline hipError_t gemm_wn_res_x3(const GemmArgs& g, bool small, hipStream_t s) {
-    if (!small && (TTS_X3_VAR & 2)) return launch_gemm<4, 2, 2, 4, TTS_WN_BK, 1, TAG_WN_RES_SKIP, 0, PIPE_DMA, true, 2, 2>(g, 1, s);
     return small ? launch_gemm<2, 2, 1, 2, TTS_WN_BK, 2, TAG_WN_RES_SKIP, 0, PIPE_DMA, true, 3, 2>(g, 1, s)
-                 : launch_gemm<4, 2, 2, 2, TTS_WN_BK, 1, TAG_WN_RES_SKIP, 0, PIPE_DMA, true, 3, 2>(g, 1, s);
+                 : launch_gemm<2, 2, 2, 2, TTS_WN_BK, 2, TAG_WN_RES_SKIP, 0, PIPE_DMA, true, 2, 2>(g, 1, s);
 }
 // fp16-operand variants (activations and weights fp16 in HBM, fp32 accumulate): same tiles and pipeline
 #ifndef TTS_H_NBUF
