@@ -30,3 +30,12 @@ def test_inv1x1_kernels_are_orthogonal(wg_cfg):
     for k in range(12):
         q = w[f'waveglow/invertible_conv-{k}/conv/kernel'][0]
         np.testing.assert_allclose(q @ q.T, np.eye(q.shape[0]), atol=1e-5)
+
+
+def test_safetensors_roundtrip(tmp_path, taco_cfg):
+    from text_to_speech_amd import weights
+    a = weights.synth_tacotron2(taco_cfg, seed=3)
+    p = tmp_path / 'w.safetensors'
+    weights.save_safetensors(p, a)
+    b = weights.load_safetensors(p)
+    assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) and b[k].dtype == np.float32 for k in a)

@@ -63,7 +63,8 @@ class Runtime(metaclass=ABCMeta):
 class HipRuntime(Runtime):
     """MI355X engine behind the reference's `compiled_infer`.
 
-    path   : a TTSW weight file (text_to_speech_amd.weights.save_ttsw), or 'synthetic' / 'synthetic:<seed>' for the
+    path   : a TTSW weight file (text_to_speech_amd.weights.save_ttsw) or a `.safetensors` file with the same tensor
+             names, or 'synthetic' / 'synthetic:<seed>' for the
              seeded synthetic weights of SURVEY.md section 8d.
     model  : 'tacotron2' | 'waveglow' | None (None: dispatch on the input dtype -- integer tokens vs float mels).
     vocoder_precision : 'f32' (exact fp32 MFMA, default) or 'f16' (fp16 GEMM operands with fp32 accumulation: the
@@ -96,7 +97,11 @@ class HipRuntime(Runtime):
         else:
             if not os.path.exists(path):
                 raise FileNotFoundError(path)
-            eng.load_weights(path)
+            if str(path).endswith('.safetensors'):
+                from . import weights
+                eng.load_state(weights.load_safetensors(path))
+            else:
+                eng.load_weights(path)
         eng.finalize()
         return eng
 

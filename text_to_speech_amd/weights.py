@@ -235,3 +235,17 @@ def load_ttsw(path) -> "OrderedDict[str, np.ndarray]":
             f.seek(o)
             out[name] = np.frombuffer(f.read(nb), dtype=np.float32).reshape(dims).copy()
     return out
+
+
+# ---- safetensors interchange (same tensor names and Keras layouts as the TTSW file) -------------------------------------
+def save_safetensors(path, tensors) -> None:
+    """Writes the manifest tensors as a `.safetensors` file (float32, contiguous), for exchange with other tooling."""
+    from safetensors.numpy import save_file
+    save_file({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in tensors.items()}, str(path))
+
+
+def load_safetensors(path) -> "OrderedDict[str, np.ndarray]":
+    """Reads a `.safetensors` file whose tensors use the manifest names (`waveglow/...`, `tacotron2/...`)."""
+    from safetensors.numpy import load_file
+    loaded = load_file(str(path))
+    return OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in sorted(loaded.items()))
