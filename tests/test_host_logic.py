@@ -266,6 +266,8 @@ def test_text_normalisation_known_answers():
         'first', 'second', 'third', 'fifth', 'twelfth', 'twentieth', 'twenty-first', 'one hundredth',
         'one hundred and first']
     assert number_to_words(1001) == 'one thousand and one' and number_to_words(110) == 'one hundred and ten'
+    assert en('The FBI and NASA, I think', to_expand_acronyms=True) == 'the af be eye and an ae as ae, i think'
+    assert en('sooooo goood', max_repetition=2) == 'soo good' and en('hello tf', replacements={'hello': 'bye'}) == 'bye tensorflow'
     fr = french_cleaners
     assert fr('Il y a 91 chats et 1 200 oiseaux le 1er mai.') == \
         'il y a quatre-vingt-onze chats et mille deux cents oiseaux le premier mai.'

@@ -289,10 +289,53 @@ def _to_ascii(text: str) -> str:
     return unicodedata.normalize('NFKD', text).encode('ascii', 'ignore').decode('ascii')
 
 
+# letter names used to spell acronyms (cleaners.py:59-86)
+_letter_names = {
+    'a': ('ha', 'ae'), 'b': ('bé', 'be'), 'c': ('cé', 'ce'), 'd': ('dé', 'de'), 'e': ('euh', 'e'), 'f': ('effe', 'af'),
+    'g': ('gé', 'ge'), 'h': ('hache', 'aich'), 'i': ('ih', 'eye'), 'j': ('ji', 'jay'), 'k': ('ka', 'kay'),
+    'l': ('elle', 'el'), 'm': ('aime', 'am'), 'n': ('aine', 'an'), 'o': ('eau', 'oo'), 'p': ('pé', 'pe'), 'q': ('cu', 'qu'),
+    'r': ('air', 'ar'), 's': ('aisse', 'as'), 't': ('thé', 'tea'), 'u': ('eu', 'yu'), 'v': ('vé', 've'),
+    'w': ('double vé', 'double yu'), 'x': ('ix', 'ex'), 'y': ('i grec', 'way'), 'z': ('zed', 'ze')}
+_acronym_re = re.compile(r"\b[A-Z]+(?!')\b")
+
+
+def expand_acronyms(text: str, lang: str) -> str:
+    """Words in capitals of at most 4 letters are spelled letter by letter (cleaners.py:211-218); 'I' stays in English."""
+    col = 0 if lang in ('fr', 'be') else 1
+
+    def spell(m):
+        w = m.group(0)
+        if len(w) > 4 or (w == 'I' and col == 1):
+            return w
+        return ' '.join(_letter_names.get(c.lower(), (c, c))[col] for c in w)
+    return _acronym_re.sub(spell, text)
+
+
+def collapse_repetitions(text: str, max_repetition: int) -> str:
+    """Keeps at most `max_repetition` consecutive copies of a character (cleaners.py:254-261)."""
+    if not text:
+        return text
+    keep, count = [text[0]], 1
+    for c in text[1:]:
+        count = 1 if c != keep[-1] else count + 1
+        if count <= max_repetition:
+            keep.append(c)
+    return ''.join(keep)
+
+
 def complete_cleaners(text: str, lang: str, *, to_lowercase=True, to_expand=True, to_expand_abrev=True,
-                      to_expand_symbols=True, **_) -> str:
-    """Restatement of cleaners.py:296-342 (acronym expansion, replacements and repetition collapsing: not needed by the
-    TTS models' default pipeline)."""
+                      to_expand_symbols=True, to_expand_acronyms=False, replacements=None, patterns=None,
+                      max_repetition=-1, **_) -> str:
+    """Restatement of cleaners.py:296-342, same order of steps."""
+    if patterns:
+        for pattern, repl in patterns.items():
+            text = re.sub(pattern, repl, text)
+    if replacements:
+        low = {k.lower(): v for k, v in replacements.items()}
+        regex = re.compile(r'\b(%s)\b' % '|'.join(re.escape(k) for k in replacements), re.IGNORECASE)
+        text = regex.sub(lambda m: low[m.group(0).lower()], text)
+    if to_expand_acronyms:
+        text = expand_acronyms(text, lang)                       # (before lower-casing, or nothing would be left to spell)
     if to_lowercase:
         text = text.lower()
     if to_expand:
@@ -308,6 +351,8 @@ def complete_cleaners(text: str, lang: str, *, to_lowercase=True, to_expand=True
         text = ''.join(c if c in keep else _to_ascii(c) for c in text)
     else:
         text = _to_ascii(text)
+    if max_repetition > 1:
+        text = collapse_repetitions(text, max_repetition)
     return re.sub(r'\s+', ' ', text).strip()
 
 
@@ -361,7 +406,8 @@ class CharTokenizer:
         return len(self.symbols)
 
     def clean_text(self, text, **kwargs):
-        allowed = ('to_lowercase', 'to_expand', 'to_expand_abrev', 'to_expand_symbols')
+        allowed = ('to_lowercase', 'to_expand', 'to_expand_abrev', 'to_expand_symbols', 'to_expand_acronyms',
+                   'replacements', 'patterns', 'max_repetition')
         return self.cleaner(text, **{k: v for k, v in kwargs.items() if k in allowed})
 
     def encode(self, text, cleaned=False):
