@@ -4,6 +4,10 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Both forms work for any N: under torchrun (WORLD_SIZE set) the process is one rank; without it `--gpus N > 1` makes this
+process a launcher that starts N rank processes itself (one per GPU, rendezvous on 127.0.0.1) BEFORE anything touches a
+GPU, forwards rank 0's JSON line and exits with the worst child status.
+
 A "step" is one pass of the hot path (tts_hip_waveglow_infer through the C ABI) over one batch of synthetic mels that is
 already resident in HBM.  With N > 1 every rank vocodes its own batch of 8 utterances (utterances are independent:
 no data-path collective, weak scaling); the timed region is bracketed by barrier + synchronize and the MAX over ranks
@@ -12,14 +16,19 @@ is reported.  Rank 0 prints ONE JSON line.
 Extra objects in the line:
   roofline     -- dominant kernel = the WN in-layer implicit GEMM (K = 3*512 + 640, N = 1024).  `achieved` = algorithmic
                   FLOPs per launch / average launch duration measured with HIP events on the engine's stream.
-  cpu_baseline -- the numpy oracle (a CPU port of the reference algorithm, NOT the reference's TF2 path, which cannot run
-                  here) timed on a bounded sample on rank 0.
+  cpu_baseline -- CPU restatements of the reference algorithm (the numpy oracle and the torch.nn.functional one -- NOT the
+                  reference's TF2 path, which cannot run here) timed on bounded samples on rank 0 at N = 1: WaveGlow with
+                  all host threads (`value`) and with one thread, Tacotron2 decode at batch 1 and 8.
+  extra        -- the other numbers BASELINE.json's metric names (batch-1 WaveGlow, Tacotron2 mel-frames/s at batch 1 / 8,
+                  fp16 modes, the configs[2] pipeline) with their own roofline fractions.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,8 +38,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+FP16_MFMA_PEAK_TFLOPS = 2500.0         # dense fp16 / bf16 matrix peak
+HBM_PEAK_TBS = 8.0                     # HBM3E
 BATCH, FRAMES = 8, 800                 # BASELINE.json configs[1]
 SAMPLE_RATE = 22050
+DECODER_STEP_BYTES_F32 = 72.73e6       # all decoder-step weights once (enc 512; SURVEY.md section 8d / BASELINE.md section 2)
+DECODER_STEP_BYTES_F16W = 72.73e6 - 0.5 * (29.36e6 + 41.94e6)   # the two LSTM matrices in fp16, the rest fp32
 
 
 K_EXECUTED = 3 * 512 + 4 * 80      # dilated k3 conv taps + conditioning folded onto 4 mel frames
@@ -57,33 +70,94 @@ def pmc_traffic_bytes(B, T):
         return None
 
 
-def cpu_baseline(wg_weights, cfg, frames: int, threads: int):
-    """Times the numpy oracle on `frames` mel frames, batch 1 (oracle = checker; here only as the reported CPU leg)."""
-    from oracle import waveglow_ref
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def _host_threads():
+    """(threads this process may run on, os.cpu_count() of the box)."""
+    box = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:                                   # pragma: no cover
+        usable = box
+    return max(1, usable), box
+
+
+def cpu_baseline(wg_weights, cfg, frames: int):
+    """CPU legs (the oracle is only the thing being TIMED here, as the reported baseline -- never the product path).
+
+    WaveGlow: `frames` mel frames at batch 1 through (a) the numpy oracle and (b) the independent torch.nn.functional
+    restatement (oneDNN / MKL: the kernel class Keras-on-TF would call), both with every usable host thread, plus (c) a
+    single-thread run of the faster one on frames / 10.  Tacotron2: 200 decoder steps (encoder and postnet included) at
+    batch 1 and 8 through both restatements.  `value` = the best all-thread WaveGlow leg."""
+    import torch
+    from oracle import tacotron2_ref, torch_ref, waveglow_ref
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import Tacotron2Config
     try:
         from threadpoolctl import threadpool_limits
     except Exception:                                   # pragma: no cover
         threadpool_limits = None
-    mel = np.random.default_rng(7).uniform(-11.5, 1.2, (1, frames, 80)).astype(np.float32)
-    z = np.random.default_rng(11).standard_normal((1, frames * 32, 8)).astype(np.float32)
+    usable, box = _host_threads()
+    threads = min(usable, 64)
+    legs = {}
 
-    def run():
+    def wg_inputs(T):
+        mel = np.random.default_rng(7).uniform(-11.5, 1.2, (1, T, 80)).astype(np.float32)
+        z = np.random.default_rng(11).standard_normal((1, T * 32, 8)).astype(np.float32)
+        return mel, z
+
+    def timed(fn):
         t0 = time.perf_counter()
-        waveglow_ref.infer(mel, wg_weights, cfg, z=z)
+        fn()
         return time.perf_counter() - t0
 
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=threads):
-            dt = run()
-    else:
-        dt = run()
+    def with_threads(n, fn):
+        torch.set_num_threads(n)
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=n):
+                return timed(fn)
+        return timed(fn)
+
+    mel, z = wg_inputs(frames)
+    with torch.no_grad():
+        dt_np = with_threads(threads, lambda: waveglow_ref.infer(mel, wg_weights, cfg, z=z))
+        dt_th = with_threads(threads, lambda: torch_ref.torch_waveglow(mel, wg_weights, cfg, z))
+        legs['waveglow_numpy_all_threads'] = {'samples_per_s': frames * 256 / dt_np, 'threads': threads, 'frames': frames,
+                                              'seconds': dt_np}
+        legs['waveglow_torch_all_threads'] = {'samples_per_s': frames * 256 / dt_th, 'threads': threads, 'frames': frames,
+                                              'seconds': dt_th}
+        small = max(8, frames // 10)
+        mel1, z1 = wg_inputs(small)
+        use_torch = dt_th <= dt_np
+        dt_1 = with_threads(1, (lambda: torch_ref.torch_waveglow(mel1, wg_weights, cfg, z1)) if use_torch
+                            else (lambda: waveglow_ref.infer(mel1, wg_weights, cfg, z=z1)))
+        legs['waveglow_single_thread'] = {'samples_per_s': small * 256 / dt_1, 'threads': 1, 'frames': small,
+                                          'seconds': dt_1, 'impl': 'torch' if use_torch else 'numpy'}
+        # Tacotron2: 100-token utterances padded to 128, 200 decoder steps, deterministic prenet (BASELINE.md section 3)
+        tcfg = Tacotron2Config()
+        tw = weights.synth_tacotron2(tcfg, seed=1234)
+        steps = 200
+        for B in (1, 8):
+            tok = np.zeros((B, 128), np.int32)
+            tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
+            dt_n = with_threads(threads, lambda: tacotron2_ref.infer(tok, tw, tcfg, max_length=steps, early_stopping=False))
+            dt_t = with_threads(threads, lambda: torch_ref.torch_tacotron2(tok, tw, tcfg, None, steps, None))
+            legs[f'tacotron2_batch{B}'] = {'mel_frames_per_s_numpy': B * steps / dt_n, 'mel_frames_per_s_torch': B * steps / dt_t,
+                                           'threads': threads, 'decoder_steps': steps, 'seconds': dt_n + dt_t}
+    torch.set_num_threads(threads)
+    best = max(legs['waveglow_numpy_all_threads']['samples_per_s'], legs['waveglow_torch_all_threads']['samples_per_s'])
+    which = 'torch.nn.functional (oneDNN/MKL)' if use_torch else 'numpy oracle (OpenBLAS)'
+    total = sum(v['seconds'] for v in legs.values())
     return {
-        'value': frames * 256 / dt, 'unit': 'audio samples/s', 'cores': threads, 'kind': 'port',
-        'sample': f'numpy oracle (OpenBLAS, {threads} threads), WaveGlow batch 1 x {frames} frames, one run of '
-                  f'{dt:.1f} s; stand-in for the reference TF2 CPU path, which cannot be imported here',
+        'value': best, 'unit': 'audio samples/s', 'cores': threads, 'kind': 'port',
+        'host_cpu_count': box, 'usable_cpus': usable,
+        'sample': f'{which} CPU restatement, WaveGlow batch 1 x {frames} frames with {threads} threads (box: os.cpu_count() = '
+                  f'{box}, {usable} usable by this process); one run per leg, {total:.1f} s of CPU work in total; stand-in for '
+                  f'the reference TF2 CPU path, which cannot be imported here',
+        'legs': legs,
     }
 
 
+# ------------------------------------------------------------------------------------------------ secondary metrics
 def secondary_metrics(eng, dev, rank):
     """The other numbers BASELINE.json's metric names (batch 1 WaveGlow; Tacotron2 mel-frames/s at batch 1 and 8),
     measured after the headline region on the same engine.  Tacotron2: 100-token utterances padded to 128, 800 decoder
@@ -91,6 +165,7 @@ def secondary_metrics(eng, dev, rank):
     import torch
     from text_to_speech_amd import weights
     from text_to_speech_amd.config import Tacotron2Config
+    from text_to_speech_amd.engine import KERNEL_WN_IN
     out = {}
     mel1 = torch.from_numpy(np.random.default_rng(3).uniform(-11.5, 1.2, (1, FRAMES, 80)).astype(np.float32)).to(dev)
     z1 = torch.from_numpy(np.random.default_rng(4).standard_normal((1, FRAMES * 32, 8)).astype(np.float32)).to(dev)
@@ -101,26 +176,31 @@ def secondary_metrics(eng, dev, rank):
     dt = (time.perf_counter() - t0) / 3
     out['waveglow_batch1_samples_per_s'] = FRAMES * 256 / dt
     # fp16-operand mode on the headline shape (BASELINE.json configs 3 / 5 run the vocoder in fp16); NOT the headline
-    # value, which stays exact fp32.  fp16 operands, fp32 accumulate: see DESIGN.md "fp16 mode".
+    # value, which stays exact fp32.  fp16 operands, fp32 accumulate: see DESIGN.md "fp16 mode".  Its waveform RMS error
+    # against the fp32 oracle is 2e-4 (above the fp32 tolerance of 1e-4): stated next to every fp16 number.
     mel8 = torch.from_numpy(np.random.default_rng(1).uniform(-11.5, 1.2, (BATCH, FRAMES, 80)).astype(np.float32)).to(dev)
     z8 = torch.from_numpy(np.random.default_rng(2).standard_normal((BATCH, FRAMES * 32, 8)).astype(np.float32)).to(dev)
-    eng.waveglow_infer(mel8, z=z8, precision='f16')
-    t0 = time.perf_counter()
-    for _ in range(3):
-        eng.waveglow_infer(mel8, z=z8, precision='f16')
-    dt = (time.perf_counter() - t0) / 3
-    out['waveglow_batch8_f16_samples_per_s'] = BATCH * FRAMES * 256 / dt
-    out['waveglow_batch8_f16_ms_per_step'] = dt * 1e3
-    # split-fp16 mode (f16x3): (hi, lo) fp16 operand planes, three MFMAs per product, fp32 accumulate -- fp32-class
-    # accuracy (5e-7 waveform RMS error against the oracle, like the exact path) on the half-precision matrix cores.
-    # Reported here, not as the headline: the headline `value` stays the exact fp32 MFMA path.
-    eng.waveglow_infer(mel8, z=z8, precision='f16x3')
-    t0 = time.perf_counter()
-    for _ in range(3):
-        eng.waveglow_infer(mel8, z=z8, precision='f16x3')
-    dt = (time.perf_counter() - t0) / 3
-    out['waveglow_batch8_f16x3_samples_per_s'] = BATCH * FRAMES * 256 / dt
-    out['waveglow_batch8_f16x3_ms_per_step'] = dt * 1e3
+    M = BATCH * FRAMES * 32
+    for prec, mult in (('f16', 1), ('f16x3', 3)):
+        # split-fp16 (f16x3): (hi, lo) fp16 operand planes, three MFMAs per product, fp32 accumulate -- fp32-class accuracy
+        # (5e-7 waveform RMS error against the oracle, like the exact path) on the half-precision matrix cores.
+        eng.waveglow_infer(mel8, z=z8, precision=prec)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.waveglow_infer(mel8, z=z8, precision=prec)
+        dt = (time.perf_counter() - t0) / 3
+        out[f'waveglow_batch8_{prec}_samples_per_s'] = BATCH * FRAMES * 256 / dt
+        out[f'waveglow_batch8_{prec}_ms_per_step'] = dt * 1e3
+        eng.kernel_timing(True)                          # HIP events on the engine stream (perturbs the step: own run)
+        eng.waveglow_infer(mel8, z=z8, precision=prec)
+        us, n = eng.kernel_time_us(KERNEL_WN_IN)
+        eng.kernel_timing(False)
+        if n:
+            tf = mult * wn_in_layer_flops(M) / (us * 1e-6) / 1e12
+            out[f'waveglow_{prec}_wn_in_layer_us'] = us
+            out[f'waveglow_{prec}_wn_in_layer_mfma_frac'] = tf / FP16_MFMA_PEAK_TFLOPS
+    out['waveglow_f16_rms_error_vs_fp32_oracle'] = 2.0e-4      # measured by tests/test_waveglow_gpu.py (tolerance 1e-4 is fp32)
+    out['waveglow_f16x3_rms_error_vs_fp32_oracle'] = 5.0e-7
     del mel8, z8
     eng.load_state(weights.synth_tacotron2(Tacotron2Config(), seed=1234))
     eng.finalize()
@@ -128,20 +208,22 @@ def secondary_metrics(eng, dev, rank):
         tok = np.zeros((B, 128), np.int32)
         tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
         tok_d = torch.from_numpy(tok).to(dev)
-        eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            eng.tacotron2_infer(tok_d, max_len=FRAMES, early_stopping=False, want_attention=False)
-        dt = (time.perf_counter() - t0) / reps
-        out[f'tacotron2_batch{B}_mel_frames_per_s'] = B * FRAMES / dt
-        out[f'tacotron2_batch{B}_us_per_decoder_step'] = 1e6 * dt / FRAMES
-        eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False, precision='f16')
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            eng.tacotron2_infer(tok_d, max_len=FRAMES, early_stopping=False, want_attention=False, precision='f16')
-        dt = (time.perf_counter() - t0) / reps
-        out[f'tacotron2_batch{B}_f16w_mel_frames_per_s'] = B * FRAMES / dt
+        for prec, tag, nbytes in (('f32', '', DECODER_STEP_BYTES_F32), ('f16', '_f16w', DECODER_STEP_BYTES_F16W)):
+            eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False, precision=prec)
+            # the call's fixed part (encoder, postnet, transfers) is separated from the per-step cost with two lengths
+            reps = 3
+            times = {}
+            for n_steps in (FRAMES // 2, FRAMES):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    eng.tacotron2_infer(tok_d, max_len=n_steps, early_stopping=False, want_attention=False, precision=prec)
+                times[n_steps] = (time.perf_counter() - t0) / reps
+            dt = times[FRAMES]
+            step_us = 1e6 * (times[FRAMES] - times[FRAMES // 2]) / (FRAMES - FRAMES // 2)
+            out[f'tacotron2_batch{B}{tag}_mel_frames_per_s'] = B * FRAMES / dt
+            out[f'tacotron2_batch{B}{tag}_us_per_decoder_step'] = 1e6 * dt / FRAMES          # whole call / steps
+            out[f'tacotron2_batch{B}{tag}_us_per_decoder_step_marginal'] = step_us            # loop only
+            out[f'tacotron2_batch{B}{tag}_decoder_hbm_frac'] = nbytes / (step_us * 1e-6) / (HBM_PEAK_TBS * 1e12)
     # BASELINE.json configs[2] shape: full text -> audio pipeline, batch 8, mixed token counts 50..200 padded to 256,
     # mel kept on the GPU between the two models, fp16 modes of both models (decoder LSTM weights fp16; WaveGlow GEMM
     # operands fp16; fp32 accumulation everywhere).
@@ -162,6 +244,51 @@ def secondary_metrics(eng, dev, rank):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without torchrun: start the N ranks ourselves.  This process never imports torch or
+    touches a GPU (a process that has initialised the GPU must not exec / be replaced, and needs none here): it only sets
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* for each child, lets rank 0 write the JSON line to our stdout and returns
+    the worst exit status."""
+    env0 = dict(os.environ)
+    env0.setdefault('MASTER_ADDR', '127.0.0.1')
+    env0.setdefault('MASTER_PORT', str(_free_port()))
+    env0.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env0['WORLD_SIZE'] = str(n)
+    env0['LOCAL_WORLD_SIZE'] = str(n)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                if deadline is None:                      # a rank died: the others would wait at a barrier forever
+                    deadline = time.time() + 20
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()                                  # exact PIDs we started
+            for p in procs:
+                p.wait()
+            procs = []
+        time.sleep(0.05)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -169,29 +296,40 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--frames', type=int, default=FRAMES)
-    ap.add_argument('--cpu-frames', type=int, default=480, help='mel frames of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=240, help='mel frames of the CPU-baseline WaveGlow sample (0 = skip)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary (untimed-region) metrics')
     ap.add_argument('--precision', default='f32', choices=('f32', 'f16x3', 'f16'),
                     help="arithmetic of the timed path: f32 = exact fp32 MFMA (default, the contract's config); "
                          "f16x3 = split fp16, fp32-class accuracy; f16 = fp16 operands")
+    ap.add_argument('--dry-run', action='store_true',
+                    help='rehearse the multi-rank plumbing on the CPU (gloo, no GPU, no HIP library): launcher, rendezvous, '
+                         'barriers, MAX-over-ranks timing and the JSON line, with a sleep as the step')
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N')
+        raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
     distributed = world > 1 or os.environ.get('TTS_BENCH_FORCE_DIST') == '1'   # (env: exercise the RCCL path at N = 1)
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from text_to_speech_amd import weights
     from text_to_speech_amd.config import WaveGlowConfig
@@ -236,7 +374,6 @@ def main():
     # secondary metrics and the CPU leg only at N = 1 (the other ranks would idle at the final barrier)
     extra = secondary_metrics(eng, dev, rank) if (rank == 0 and world == 1 and not args.no_extra) else None
     samples = world * B * T * 256 * args.steps
-    result = None
     if rank == 0:
         M = B * T * 32
         roofline = None
@@ -244,7 +381,8 @@ def main():
             # fp16 matrix pipe (2.5 PFLOP/s dense): the split mode issues three MFMAs per product
             mfma_flops = wn_in_layer_flops(M) * (3 if args.precision == 'f16x3' else 1)
             achieved = mfma_flops / (avg_us * 1e-6) / 1e12
-            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': achieved / 2500.0,
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved / FP16_MFMA_PEAK_TFLOPS,
                         'flops_per_launch': mfma_flops, 'traffic': None, 'launches_timed': launches,
                         'avg_launch_us': avg_us,
                         'kernel': 'WN in-layer implicit GEMM, fp16 MFMA (' + args.precision + ')'}
@@ -261,8 +399,7 @@ def main():
                         'avg_launch_us': avg_us}
         cpu = None
         if args.cpu_frames > 0 and world == 1:
-            threads = min(os.cpu_count() or 1, 16)
-            cpu = cpu_baseline(w, cfg, args.cpu_frames, threads)
+            cpu = cpu_baseline(w, cfg, args.cpu_frames)
         result = {
             'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)' if args.precision == 'f32' else
                       f'audio samples/sec (22.05 kHz WaveGlow vocoding, {args.precision})',
@@ -272,6 +409,7 @@ def main():
             'config': {'workload': f'WaveGlow-only vocoding of precomputed 80x{T} mel, batch {B} per GPU, fp32 '
                                    f'(BASELINE.json configs[1])', 'batch_per_gpu': B, 'mel_frames': T,
                        'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
+                       'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
                        'weights': 'seeded synthetic (rng 1234)'},
             'x_realtime': samples / dt / SAMPLE_RATE,
             'roofline': roofline, 'cpu_baseline': cpu, 'extra': extra,
@@ -281,6 +419,43 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def dry_run(args, world, rank):
+    """CPU rehearsal of the rank plumbing (tests/test_bench_launcher.py): gloo instead of RCCL, a sleep instead of the HIP
+    step.  Prints a line of the same shape marked "dry_run": true -- never a measurement."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))                     # rank-dependent: MAX over ranks must pick the slowest
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        B, T = args.batch, args.frames
+        samples = world * B * T * 256 * args.steps
+        print(json.dumps({'metric': 'dry run (no GPU work)', 'dry_run': True, 'value': samples / dt, 'unit': 'audio samples/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision,
+                          'data': 'synthetic', 'config': {'workload': 'dry run', 'world_size': world, 'backend': 'gloo'},
+                          'roofline': None, 'cpu_baseline': None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

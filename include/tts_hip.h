@@ -56,6 +56,11 @@ int tts_hip_abi_version(void);
 int tts_hip_set_tensor(tts_hip_engine* e, const char* name, const float* data, const int64_t* dims, int ndim);
 int tts_hip_load_weights(tts_hip_engine* e, const char* ttsw_path);
 int tts_hip_finalize(tts_hip_engine* e);
+/* Validates the container structure of a TTSW file (magic, version, entry table, dims, payload ranges against the file
+ * size) without an engine or a GPU; 0 if `tts_hip_load_weights` would accept it, else TTS_HIP_EIO / TTS_HIP_ENOMEM with the
+ * reason in `errbuf` (may be NULL).  The reference's loader trusts its checkpoint files
+ * (custom_train_objects/checkpoint_manager.py:169-215); a C loader cannot.                                           */
+int tts_hip_check_weights_file(const char* ttsw_path, char* errbuf, int errbuf_len);
 /* 1 if the model ("waveglow" | "tacotron2" | "mel_stft") is ready to run, else 0. */
 int tts_hip_has_model(const tts_hip_engine* e, const char* model);
 

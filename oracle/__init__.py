@@ -10,5 +10,6 @@ Pinning status:
   * `waveglow_ref`, `tacotron2_ref` -- PARITY UNPINNED: the reference has no test, golden vector or checkpoint for these
                        and cannot be imported here (Keras 3 is not installed: ordinary ModuleNotFoundError, nothing was
                        denied).  They restate the reference source line by line (file:line cited per function) and are
-                       cross-checked by an independent torch.nn.functional restatement in tests/test_oracle_crosscheck.py.
+                       cross-checked by an independent torch.nn.functional restatement (oracle/torch_ref.py,
+                       tests/test_oracle_crosscheck.py).
 """

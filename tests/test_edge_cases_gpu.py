@@ -109,6 +109,35 @@ def test_engine_without_weights_reports_not_ready():
         eng.close()
 
 
+def test_wrong_shape_tensors_are_rejected_at_finalize(taco_weights):
+    """Every Tacotron2 tensor is indexed with fixed extents after finalize: a right name with a wrong shape must be an
+    EINVAL at finalize (with the tensor named), not a host over-read or an undersized device buffer."""
+    from text_to_speech_amd.engine import HipEngine
+    from text_to_speech_amd import HipLibraryError
+    bad = {
+        'tacotron2/encoder/bi_lstm/forward/kernel': (512, 512),
+        'tacotron2/decoder/attention_rnn/kernel': (768, 2048),
+        'tacotron2/decoder/decoder_rnn/cell_0/recurrent_kernel': (512, 4096),
+        'tacotron2/decoder/lsa/location_conv/kernel': (31, 2, 16),
+        'tacotron2/decoder/gate_output/kernel': (1024, 1),
+        'tacotron2/decoder/prenet/layer_1/kernel': (256, 128),
+        'tacotron2/postnet/norm_3/moving_variance': (80,),
+    }
+    for name, shape in bad.items():
+        assert tuple(taco_weights[name].shape) != shape
+        eng = HipEngine(0)
+        try:
+            eng.load_state(taco_weights)
+            eng.set_tensor(name, np.zeros(shape, np.float32))
+            with pytest.raises(HipLibraryError) as ei:
+                eng.finalize()
+            tail = name.split('/', 1)[1].rsplit('/', 1)[0]
+            assert tail in str(ei.value) or 'unsupported' in str(ei.value), str(ei.value)
+            assert not eng.has_model('tacotron2')
+        finally:
+            eng.close()
+
+
 def test_ttsw_file_roundtrip_through_c_loader(tmp_path, gpu_engine, taco_weights, taco_cfg):
     """tts_hip_load_weights reads the same TTSW file weights.save_ttsw writes."""
     from text_to_speech_amd import weights

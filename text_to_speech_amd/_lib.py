@@ -15,7 +15,7 @@ LIB_NAME = 'libtts_hip.so'
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):
@@ -31,6 +31,7 @@ SIGNATURES = {
     'tts_hip_set_tensor': (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     'tts_hip_load_weights': (c_int, [c_void_p, c_char_p]),
     'tts_hip_finalize': (c_int, [c_void_p]),
+    'tts_hip_check_weights_file': (c_int, [c_char_p, c_char_p, c_int]),
     'tts_hip_has_model': (c_int, [c_void_p, c_char_p]),
     'tts_hip_waveglow_infer': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int]),
     'tts_hip_waveglow_infer_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int]),

@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstring>
+#include <exception>
 
 int set_err(const tts_hip_engine* e, int code, const char* fmt, ...) {
     char buf[1024];
@@ -71,7 +72,7 @@ void timing_collect(tts_hip_engine* e) {
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 4; }
+int tts_hip_abi_version(void) { return 5; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -110,60 +111,122 @@ int tts_hip_destroy(tts_hip_engine* e) {
 
 const char* tts_hip_last_error(const tts_hip_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
+// numel of `dims` if every dim is positive and the product stays below kMaxTensorElems (2^34 floats = 64 GiB); 0 otherwise
+static size_t checked_numel(const std::vector<int64_t>& dims) {
+    constexpr uint64_t kMaxTensorElems = 1ull << 34;
+    uint64_t n = 1;
+    for (int64_t d : dims) {
+        if (d <= 0 || (uint64_t)d > kMaxTensorElems) return 0;
+        n *= (uint64_t)d;
+        if (n > kMaxTensorElems) return 0;
+    }
+    return (size_t)n;
+}
+
 int tts_hip_set_tensor(tts_hip_engine* e, const char* name, const float* data, const int64_t* dims, int ndim) {
     if (!e || !name || !data || !dims || ndim <= 0 || ndim > 8) return set_err(e, TTS_HIP_EINVAL, "set_tensor: bad argument");
-    HostTensor t;
-    t.dims.assign(dims, dims + ndim);
-    for (auto d : t.dims)
-        if (d <= 0) return set_err(e, TTS_HIP_EINVAL, "set_tensor(%s): non-positive dim", name);
-    t.data.assign(data, data + t.numel());
-    e->host[name] = std::move(t);
+    try {
+        HostTensor t;
+        t.dims.assign(dims, dims + ndim);
+        const size_t n = checked_numel(t.dims);
+        if (!n) return set_err(e, TTS_HIP_EINVAL, "set_tensor(%s): non-positive or oversized dim", name);
+        t.data.assign(data, data + n);
+        e->host[name] = std::move(t);
+    } catch (const std::exception& ex) {                       // bad_alloc / length_error must not cross the C boundary
+        return set_err(e, TTS_HIP_ENOMEM, "set_tensor(%s): %s", name, ex.what());
+    }
     return TTS_HIP_OK;
 }
 
-int tts_hip_load_weights(tts_hip_engine* e, const char* path) {
-    if (!e || !path) return TTS_HIP_EINVAL;
+// Parses a TTSW file into `out` (may be null: validation only).  Nothing in the file is trusted: the entry count, name
+// lengths, dims and payload ranges are all checked against the file size before anything is allocated from them.
+static int parse_ttsw(const char* path, std::map<std::string, HostTensor>* out, std::string* err) {
     FILE* f = fopen(path, "rb");
-    if (!f) return set_err(e, TTS_HIP_EIO, "cannot open %s", path);
+    if (!f) {
+        *err = std::string("cannot open ") + path;
+        return TTS_HIP_EIO;
+    }
     auto fail = [&](const char* what) {
         fclose(f);
-        return set_err(e, TTS_HIP_EIO, "%s: %s", path, what);
+        *err = std::string(path) + ": " + what;
+        return TTS_HIP_EIO;
     };
+    if (fseek(f, 0, SEEK_END) != 0) return fail("cannot seek");
+    const long long fsize = ftell(f);
+    if (fsize < 12 || fseek(f, 0, SEEK_SET) != 0) return fail("not a TTSW file");
     char magic[4];
     uint32_t ver = 0, n = 0;
     if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "TTSW", 4) != 0) return fail("not a TTSW file");
     if (fread(&ver, 4, 1, f) != 1 || fread(&n, 4, 1, f) != 1 || ver != 1) return fail("unsupported version");
+    // an entry header is at least 4 + 1 + 4 + 8 + 8 + 8 = 33 bytes
+    if ((unsigned long long)n * 33ull > (unsigned long long)fsize) return fail("entry count exceeds file size");
     struct Ent {
         std::string name;
         std::vector<int64_t> dims;
         uint64_t off, nbytes;
     };
-    std::vector<Ent> ents(n);
-    for (auto& en : ents) {
-        uint32_t ln = 0, nd = 0;
-        if (fread(&ln, 4, 1, f) != 1 || ln > 4096) return fail("bad name length");
-        en.name.resize(ln);
-        if (fread(&en.name[0], 1, ln, f) != ln) return fail("truncated header");
-        if (fread(&nd, 4, 1, f) != 1 || nd == 0 || nd > 8) return fail("bad ndim");
-        en.dims.resize(nd);
-        if (fread(en.dims.data(), 8, nd, f) != nd) return fail("truncated header");
-        if (fread(&en.off, 8, 1, f) != 1 || fread(&en.nbytes, 8, 1, f) != 1) return fail("truncated header");
-    }
-    for (auto& en : ents) {
-        HostTensor t;
-        t.dims = en.dims;
-        if (t.numel() * sizeof(float) != en.nbytes) return fail("size mismatch");
-        t.data.resize(t.numel());
-        if (fseek(f, (long)en.off, SEEK_SET) != 0 || fread(t.data.data(), 1, en.nbytes, f) != en.nbytes)
-            return fail("truncated payload");
-        e->host[en.name] = std::move(t);
+    try {
+        std::vector<Ent> ents(n);
+        for (auto& en : ents) {
+            uint32_t ln = 0, nd = 0;
+            if (fread(&ln, 4, 1, f) != 1 || ln == 0 || ln > 4096) return fail("bad name length");
+            en.name.resize(ln);
+            if (fread(&en.name[0], 1, ln, f) != ln) return fail("truncated header");
+            if (fread(&nd, 4, 1, f) != 1 || nd == 0 || nd > 8) return fail("bad ndim");
+            en.dims.resize(nd);
+            if (fread(en.dims.data(), 8, nd, f) != nd) return fail("truncated header");
+            if (fread(&en.off, 8, 1, f) != 1 || fread(&en.nbytes, 8, 1, f) != 1) return fail("truncated header");
+            const size_t numel = checked_numel(en.dims);
+            if (!numel) return fail("non-positive or oversized dim");
+            if ((uint64_t)numel * sizeof(float) != en.nbytes) return fail("size mismatch");
+            if (en.off > (uint64_t)fsize || en.nbytes > (uint64_t)fsize - en.off) return fail("payload outside the file");
+        }
+        for (auto& en : ents) {
+            if (!out) continue;
+            HostTensor t;
+            t.dims = en.dims;
+            t.data.resize(en.nbytes / sizeof(float));
+            if (fseek(f, (long)en.off, SEEK_SET) != 0 || fread(t.data.data(), 1, en.nbytes, f) != en.nbytes)
+                return fail("truncated payload");
+            (*out)[en.name] = std::move(t);
+        }
+    } catch (const std::exception& ex) {
+        fclose(f);
+        *err = std::string(path) + ": " + ex.what();
+        return TTS_HIP_ENOMEM;
     }
     fclose(f);
     return TTS_HIP_OK;
 }
 
+int tts_hip_load_weights(tts_hip_engine* e, const char* path) {
+    if (!e || !path) return TTS_HIP_EINVAL;
+    std::string err;
+    const int rc = parse_ttsw(path, &e->host, &err);
+    if (rc) return set_err(e, rc, "%s", err.c_str());
+    return TTS_HIP_OK;
+}
+
+int tts_hip_check_weights_file(const char* path, char* errbuf, int errbuf_len) {
+    if (!path) return TTS_HIP_EINVAL;
+    std::string err;
+    const int rc = parse_ttsw(path, nullptr, &err);
+    if (errbuf && errbuf_len > 0) snprintf(errbuf, (size_t)errbuf_len, "%s", err.c_str());
+    return rc;
+}
+
+static int finalize_impl(tts_hip_engine* e);
+
 int tts_hip_finalize(tts_hip_engine* e) {
     if (!e) return TTS_HIP_EINVAL;
+    try {
+        return finalize_impl(e);
+    } catch (const std::exception& ex) {
+        return set_err(e, TTS_HIP_ENOMEM, "finalize: %s", ex.what());
+    }
+}
+
+static int finalize_impl(tts_hip_engine* e) {
     HIPCHK(e, hipSetDevice(e->device));
     int rc;
     bool has_wg = false, has_taco = false;

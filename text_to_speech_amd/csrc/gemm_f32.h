@@ -20,7 +20,34 @@
 #include <atomic>
 #include <stdint.h>
 
+// Timing ablations of the fp16 loop (TTS_ABL = 1..6; results are garbage when set) only exist in a build made with
+// -DTTS_DEBUG_HOOKS -DTTS_ABL=n; csrc/build.sh never passes either.
+#ifndef TTS_DEBUG_HOOKS
+#undef TTS_ABL
+#endif
+#ifndef TTS_ABL
+#define TTS_ABL 0
+#endif
+
 namespace ttsgemm {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only, and one process may own engines on
+// several GPUs: one flag per (kernel instantiation, device).  Two host threads may race here (stream(overlap=True) drives
+// two handles): the flags are atomic and setting the attribute twice is harmless.
+struct PerDeviceOnce {
+    static constexpr int kMaxDevices = 64;
+    std::atomic<bool> set[kMaxDevices];
+};
+inline hipError_t set_max_dyn_lds_once(const void* kern, size_t lds, PerDeviceOnce& once) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < PerDeviceOnce::kMaxDevices;
+    if (tracked && once.set[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && tracked) once.set[dev].store(true, std::memory_order_release);
+    return e;
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -412,7 +439,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         f32x4 fa[RT], fb[CT];
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-#ifdef TTS_ABL
+#if TTS_ABL
             if (HALF && (TTS_ABL == 5 || TTS_ABL == 6)) { fa[i] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(i + k8); continue; }   // ablation: no A-side LDS reads
 #endif
             fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
@@ -443,7 +470,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         // NBUF (3 or 4) LDS buffers.  Step t: issue tile t+NBUF-1's DMA into the buffer read at step t-1 (every wave has
         // passed the barrier that ended that step), run tile t's MFMAs, then wait until all but the newest NBUF-2 tiles'
         // DMA have landed (counted vmcnt: tile t+1 is in LDS) and barrier.  No VGPR staging, no ds_write.
-#ifdef TTS_ABL
+#if TTS_ABL
         constexpr int LT = PL * ((HALF && (TTS_ABL == 4 || TTS_ABL == 6)) ? PB : PA + PB);
 #else
         constexpr int LT = PL * (PA + PB);           // DMA instructions per tile per wave
@@ -453,7 +480,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             fetch_next([&](bool isA, int p, const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned pofs) {
                 // wave-uniform LDS base of this instruction's 16 rows; lane l lands at base + 16 * l
                 float* dst = (isA ? As + buf * PL * BM * LDSK : Bs + buf * PL * BN * LDSK) + (p * RPP + wave * 16) * LDSK;
-#ifdef TTS_ABL
+#if TTS_ABL
                 if (HALF && (TTS_ABL == 4 || TTS_ABL == 6) && isA) return;       // ablation: no A-side DMA
 #endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
@@ -472,9 +499,6 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0, bufn = NBUF - 1;                // buffer of tile t, buffer for tile t + NBUF - 1
-#ifndef TTS_ABL
-#define TTS_ABL 0
-#endif
         constexpr int ABL = HALF ? TTS_ABL : 0;      // timing ablations of the fp16 loop (results are garbage when != 0)
         for (int t = 0; t < nAll; ++t) {
             if (ABL != 2) dma_tile(bufn);
@@ -715,12 +739,8 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
     auto kern = gemm_f32_kernel<WR, WC, RT, CT, BK, OCC, TAG, NI, PIPE, HALF, NBD, PL>;
     // two engine handles may launch from two host threads (stream(overlap=True)): the flag is atomic, and setting the
     // attribute twice is harmless
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set.store(true, std::memory_order_release);
-    }
+    static PerDeviceOnce attr_set;
+    if (hipError_t e = set_max_dyn_lds_once((const void*)kern, lds, attr_set); e != hipSuccess) return e;
     dim3 grid(numMt8 * numNt, 1, batch_z);
     hipLaunchKernelGGL(kern, grid, dim3(WR * WC * 64), lds, stream, g);
     return hipGetLastError();

@@ -38,10 +38,12 @@ constexpr int CHUNK = 32;             // decoder steps per hipGraph replay
 
 struct __attribute__((aligned(32))) DecState {   // device-resident loop state (one per call); one 32-byte scalar load
     int t0;                           // first step of the current chunk
-    int n_finished;                   // rows whose stop token has fired
+    int n_fin[2];                     // rows whose stop token has fired, in two parity slots: the kernels of step t read
+                                      // slot t & 1 and the stop-token wave of step t writes slot (t + 1) & 1, so the value a
+                                      // launch decides `done` from cannot change while that launch is running
     int steps_run;                    // loop iterations executed so far
     int B, max_len, early_stop;
-    int pad[2];
+    int pad;
 };
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -191,7 +193,8 @@ __global__ void enc_len_kernel(const uint8_t* __restrict__ mask, int* __restrict
 // Branch-free on purpose: with short-circuit evaluation every field became its own dependent scalar load + wait + branch
 // (4-5 sequential ~0.3 us round trips at the head or tail of every step kernel); this way all fields arrive with one load.
 __device__ __forceinline__ bool step_done(const DecState* st, int j, int& t) {
-    const int t0 = st->t0, nf = st->n_finished, nb = st->B, ml = st->max_len, es = st->early_stop;
+    const int t0 = st->t0, nf0 = st->n_fin[0], nf1 = st->n_fin[1], nb = st->B, ml = st->max_len, es = st->early_stop;
+    const int nf = (j & 1) ? nf1 : nf0;           // CHUNK is even: the parity of t equals the parity of j
     t = t0 + j;
     return (t >= ml) | ((es != 0) & (nf >= nb));
 }
@@ -680,6 +683,8 @@ __global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st,
     int t;
     const bool done = step_done(st, j, t);        // requested up front (with max_len), consulted before the stores
     const int max_len = st->max_len;
+    const int nf_cur = st->n_fin[j & 1];
+    int newly = 0;                                           // rows whose stop token fires in this step (stop wave only)
     for (int b0 = 0; b0 < B; b0 += NB) {
         const int bw = b0 + (lane >> 3);                     // batch row this lane will write
         const int fin_old = (o == NMEL && (lane & 7) == 0 && bw < B) ? finished[bw] : 0;
@@ -721,6 +726,7 @@ __global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st,
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 1, 64);
         const int b = bw;                                    // lane l holds batch row l >> 3 of this chunk
+        bool fired = false;
         if ((lane & 7) == 0 && b < B && !done) {
             v += bias;
             if (o < NMEL) {
@@ -734,20 +740,25 @@ __global__ __launch_bounds__(256) void project_kernel(DecState* __restrict__ st,
                 if (!fin && sp > 0.5f) {
                     fin = 1;
                     finished[b] = 1;
-                    atomicAdd(&st->n_finished, 1);
+                    fired = true;
                 }
                 if (!fin) lengths[b] += 1;
                 if (b == B - 1) st->steps_run = t + 1;
             }
         }
+        if (o == NMEL) newly += __popcll(__ballot(fired));   // o is wave-uniform
     }
+    // hand the count to the next step through the other parity slot (also when this step did nothing, so that the slot the
+    // next step reads is never stale): nobody reads that slot during this launch
+    if (o == NMEL && lane == 0) st->n_fin[(j & 1) ^ 1] = nf_cur + newly;
 }
 
 __global__ void advance_chunk_kernel(DecState* st) { st->t0 += CHUNK; }
 
 __global__ void init_state_kernel(DecState* st, int B, int max_len, int early_stop) {
     st->t0 = 0;
-    st->n_finished = 0;
+    st->n_fin[0] = 0;
+    st->n_fin[1] = 0;
     st->steps_run = 0;
     st->B = B;
     st->max_len = max_len;
@@ -793,8 +804,11 @@ int fold_conv_bn(tts_hip_engine* e, const std::string& conv, const std::string& 
     const HostTensor* mu = find_tensor(e, norm + "/moving_mean");
     const HostTensor* va = find_tensor(e, norm + "/moving_variance");
     if (!k || !b || !ga || !be || !mu || !va) return set_err(e, TTS_HIP_ENOTREADY, "missing tensors of %s", conv.c_str());
-    if (k->dims != std::vector<int64_t>{5, cin, cout} || (int)b->numel() != cout || (int)ga->numel() != cout)
-        return set_err(e, TTS_HIP_EINVAL, "unexpected shape for %s", conv.c_str());
+    const std::vector<int64_t> vec{cout};
+    if (k->dims != std::vector<int64_t>{5, cin, cout} || b->dims != vec || ga->dims != vec || be->dims != vec ||
+        mu->dims != vec || va->dims != vec)
+        return set_err(e, TTS_HIP_EINVAL, "unexpected shape for %s / %s (kernel [5, %d, %d], vectors [%d])", conv.c_str(),
+                       norm.c_str(), cin, cout, cout);
     const int cin_pad = (cin + 31) / 32 * 32;
     out->cin = cin;
     out->cin_pad = cin_pad;
@@ -894,12 +908,8 @@ hipError_t launch_lstm(hipStream_t s, const DecState* st, int j, const LstmDev& 
                        const float* s1, int n1, const float* h_old, float* h_new, float* c_state, int B) {
     const size_t lds = (size_t)NBT * 256 * KS * sizeof(float);
     auto kern = lstm_step_kernel<KS, NBT, HW>;
-    static std::atomic<bool> attr{false};
-    if (!attr.load(std::memory_order_acquire)) {
-        hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (er != hipSuccess) return er;
-        attr.store(true, std::memory_order_release);
-    }
+    static PerDeviceOnce attr;
+    if (hipError_t er = set_max_dyn_lds_once((const void*)kern, lds, attr); er != hipSuccess) return er;
     const void* W = HW ? (const void*)L.W16 : (const void*)L.W;
     hipLaunchKernelGGL(kern, dim3(L.units / 4), dim3(256), lds, s, st, j, W, L.b, s0, n0, s1, n1, h_old, h_new,
                        c_state, B, L.units);
@@ -968,24 +978,34 @@ int tacotron2_finalize(tts_hip_engine* e) {
     auto& al = tc.allocs;
     int rc;
     auto get = [&](const char* name) { return find_tensor(e, std::string("tacotron2/") + name); };
-#define NEED(var, name)                                                                     \
+    // every tensor is indexed with fixed extents below, so its dims are checked here (like `need` in waveglow_finalize)
+    auto dims_str = [](const std::vector<int64_t>& d) {
+        std::string r = "[";
+        for (size_t i = 0; i < d.size(); ++i) r += (i ? ", " : "") + std::to_string((long long)d[i]);
+        return r + "]";
+    };
+#define NEED(var, name, ...)                                                                \
     const HostTensor* var = get(name);                                                      \
-    if (!var) { tacotron2_free(e); return set_err(e, TTS_HIP_ENOTREADY, "missing tensor tacotron2/%s", name); }
+    if (!var) { tacotron2_free(e); return set_err(e, TTS_HIP_ENOTREADY, "missing tensor tacotron2/%s", name); }      \
+    if (var->dims != std::vector<int64_t>{__VA_ARGS__}) {                                   \
+        tacotron2_free(e);                                                                  \
+        return set_err(e, TTS_HIP_EINVAL, "tacotron2/%s has shape %s, expected %s", name, dims_str(var->dims).c_str(), \
+                       dims_str(std::vector<int64_t>{__VA_ARGS__}).c_str());                \
+    }
 #define TCHK(x) if ((rc = (x))) { tacotron2_free(e); return rc; }
-    NEED(emb, "encoder/embeddings");
-    if (emb->dims != std::vector<int64_t>{148, 512}) { tacotron2_free(e); return set_err(e, TTS_HIP_EINVAL, "embeddings must be [148, 512]"); }
+    NEED(emb, "encoder/embeddings", 148, 512);
     TCHK(upload(e, emb->data.data(), emb->numel(), &tc.embeddings, al));
     for (int i = 0; i < 3; ++i) {
         const std::string s = std::to_string(i + 1);
         TCHK(fold_conv_bn(e, "tacotron2/encoder/conv_" + s, "tacotron2/encoder/norm_" + s, 512, 512, &tc.enc_conv[i], al));
     }
     {   // BiLSTM: one N = 2048 input projection (forward | backward), recurrent kernels kept in Keras layout
-        NEED(kf, "encoder/bi_lstm/forward/kernel");
-        NEED(kb, "encoder/bi_lstm/backward/kernel");
-        NEED(rf, "encoder/bi_lstm/forward/recurrent_kernel");
-        NEED(rb, "encoder/bi_lstm/backward/recurrent_kernel");
-        NEED(bf, "encoder/bi_lstm/forward/bias");
-        NEED(bb, "encoder/bi_lstm/backward/bias");
+        NEED(kf, "encoder/bi_lstm/forward/kernel", 512, 1024);
+        NEED(kb, "encoder/bi_lstm/backward/kernel", 512, 1024);
+        NEED(rf, "encoder/bi_lstm/forward/recurrent_kernel", 256, 1024);
+        NEED(rb, "encoder/bi_lstm/backward/recurrent_kernel", 256, 1024);
+        NEED(bf, "encoder/bi_lstm/forward/bias", 1024);
+        NEED(bb, "encoder/bi_lstm/backward/bias", 1024);
         std::vector<float> Bt((size_t)2048 * 512), bias(2048);
         for (int n = 0; n < 1024; ++n) {
             for (int k = 0; k < 512; ++k) {
@@ -1000,8 +1020,8 @@ int tacotron2_finalize(tts_hip_engine* e) {
         TCHK(upload(e, rf->data.data(), rf->numel(), &tc.bl_rec[0], al));
         TCHK(upload(e, rb->data.data(), rb->numel(), &tc.bl_rec[1], al));
     }
-    NEED(p0, "decoder/prenet/layer_0/kernel");
-    NEED(p1, "decoder/prenet/layer_1/kernel");
+    NEED(p0, "decoder/prenet/layer_0/kernel", NMEL, PRE);
+    NEED(p1, "decoder/prenet/layer_1/kernel", PRE, PRE);
     {   // layer 0: Keras [80][256] -> [k / 4][256][4]
         std::vector<float> w0p((size_t)NMEL * PRE);
         for (int k = 0; k < NMEL; ++k)
@@ -1009,16 +1029,18 @@ int tacotron2_finalize(tts_hip_engine* e) {
         TCHK(upload(e, w0p.data(), w0p.size(), &tc.prenet_w0, al));
     }
     TCHK(upload_transposed(e, p1, PRE, PRE, PRE, &tc.prenet_w1, al));
-    NEED(ak, "decoder/attention_rnn/kernel");
-    NEED(ar, "decoder/attention_rnn/recurrent_kernel");
-    NEED(ab, "decoder/attention_rnn/bias");
-    const int enc = (int)ak->dims[0] - PRE;
+    const HostTensor* ak0 = get("decoder/attention_rnn/kernel");
+    if (!ak0) { tacotron2_free(e); return set_err(e, TTS_HIP_ENOTREADY, "missing tensor tacotron2/decoder/attention_rnn/kernel"); }
+    const int enc = ak0->dims.size() == 2 ? (int)ak0->dims[0] - PRE : -1;    // 512, or 768 with a 256-d speaker embedding
     if (enc != 512 && enc != 768) { tacotron2_free(e); return set_err(e, TTS_HIP_EINVAL, "encoder width %d unsupported (512 or 768)", enc); }
     tc.enc_dim = enc;
     tc.spk_dim = enc - 512;
-    NEED(dk, "decoder/decoder_rnn/cell_0/kernel");
-    NEED(dr, "decoder/decoder_rnn/cell_0/recurrent_kernel");
-    NEED(db, "decoder/decoder_rnn/cell_0/bias");
+    NEED(ak, "decoder/attention_rnn/kernel", PRE + enc, 4 * ARNN);
+    NEED(ar, "decoder/attention_rnn/recurrent_kernel", ARNN, 4 * ARNN);
+    NEED(ab, "decoder/attention_rnn/bias", 4 * ARNN);
+    NEED(dk, "decoder/decoder_rnn/cell_0/kernel", ARNN + enc, 4 * DRNN);
+    NEED(dr, "decoder/decoder_rnn/cell_0/recurrent_kernel", DRNN, 4 * DRNN);
+    NEED(db, "decoder/decoder_rnn/cell_0/bias", 4 * DRNN);
     {
         DevBuf s1, s2, s3;
         auto pack = [&](const HostTensor* k, const HostTensor* r, const HostTensor* b, int kin, LstmDev* L) -> int {
@@ -1048,11 +1070,11 @@ int tacotron2_finalize(tts_hip_engine* e) {
         s3.release();
         TCHK(rc);
     }
-    NEED(qk, "decoder/lsa/query_layer/kernel");       // [1024][128]
-    NEED(mk, "decoder/lsa/memory_layer/kernel");      // [enc][128]
-    NEED(vk, "decoder/lsa/value_layer/kernel");       // [128][1]
-    NEED(lc, "decoder/lsa/location_conv/kernel");     // [31][2][32]
-    NEED(ld, "decoder/lsa/location_dense/kernel");    // [32][128]
+    NEED(qk, "decoder/lsa/query_layer/kernel", ARNN, ATT);
+    NEED(mk, "decoder/lsa/memory_layer/kernel", enc, ATT);
+    NEED(vk, "decoder/lsa/value_layer/kernel", ATT, 1);
+    NEED(lc, "decoder/lsa/location_conv/kernel", LOCK, 2, 32);
+    NEED(ld, "decoder/lsa/location_dense/kernel", 32, ATT);
     TCHK(upload_transposed(e, qk, ARNN, ATT, ARNN, &tc.query_w, al));      // [128][1024]: one attention dim per row
     TCHK(upload_transposed(e, mk, enc, ATT, enc, &tc.memory_Bt, al));
     TCHK(upload(e, vk->data.data(), vk->numel(), &tc.value_w, al));
@@ -1066,10 +1088,10 @@ int tacotron2_finalize(tts_hip_engine* e) {
             }
         TCHK(upload(e, wl.data(), wl.size(), &tc.loc_dense, al));
     }
-    NEED(lk, "decoder/linear_projection/kernel");
-    NEED(lb, "decoder/linear_projection/bias");
-    NEED(gk, "decoder/gate_output/kernel");
-    NEED(gb, "decoder/gate_output/bias");
+    NEED(lk, "decoder/linear_projection/kernel", DRNN + enc, NMEL);
+    NEED(lb, "decoder/linear_projection/bias", NMEL);
+    NEED(gk, "decoder/gate_output/kernel", DRNN + enc, 1);
+    NEED(gb, "decoder/gate_output/bias", 1);
     {
         const int K = DRNN + enc;
         std::vector<float> pw((size_t)(NMEL + 1) * K), pb(NMEL + 1);
@@ -1294,8 +1316,13 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     // Measurement hook (results are garbage when set): TTS_HIP_DEBUG_ONLY_KERNEL=k launches only step kernel k (0 prenet,
     // 1 attention LSTM, 2 query, 3 energies, 4 softmax_ctx, 5 decoder LSTM, 6 project) seven times per step, which gives
     // that kernel's cost inside the graph without the other six around it (scripts/run_taco.py prints the step time).
+    // Only exists in a build made with -DTTS_DEBUG_HOOKS (csrc/build.sh never passes it).
+#ifdef TTS_DEBUG_HOOKS
     const char* only_env = getenv("TTS_HIP_DEBUG_ONLY_KERNEL");
     const int only = only_env ? atoi(only_env) : -1;
+#else
+    constexpr int only = -1;
+#endif
     auto enqueue_step = [&](int j) -> int {
         const int par = j & 1;                       // CHUNK is even, so the parity of t equals the parity of j
         float* hatt_old = d_hatt + (size_t)par * B * ARNN;
@@ -1365,7 +1392,11 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     {
         // chunks of CHUNK steps; after each chunk the host reads the loop state (one 24-byte copy)
         DecState h{};
+#ifdef TTS_DEBUG_HOOKS
         const bool use_graph = !e->timing && getenv("TTS_HIP_NO_GRAPH") == nullptr;
+#else
+        const bool use_graph = !e->timing;           // per-step HIP events (tts_hip_kernel_timing) cannot be captured
+#endif
         hipGraph_t graph = nullptr;
         hipGraphExec_t gexec = nullptr;
         if (use_graph) {
@@ -1396,7 +1427,7 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
                 return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
             }
             host_steps = h.steps_run;
-            if (early_stop && h.n_finished >= B) break;
+            if (early_stop && h.n_fin[0] >= B) break;      // the last step of a chunk (odd j) wrote slot 0
         }
         if (gexec) (void)hipGraphExecDestroy(gexec);
         if (graph) (void)hipGraphDestroy(graph);

@@ -731,7 +731,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     // short utterances (a sentence at batch 1): 64-row tiles when they save padding
     const int pr_big = tile128 ? pr128 : pr256;
     const bool row64 = x3 ? pr64 * 1.25 < pr256      // split fp16 has two tile shapes: 64 x 128 (about 25 % more time per row) and 256 x 256
-                          : BT <= 512 && getenv("TTS_HIP_NO_ROW64") == nullptr &&
+                          : BT <= 512 &&
                             (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
     const int PR = row64 ? pr64 : (tile128 && !x3) ? pr128 : pr256;
     const int NP = x3 ? 2 : 1;                                   // fp16 planes per operand
