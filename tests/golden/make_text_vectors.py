@@ -124,6 +124,12 @@ def main():
     for texts, n in merges:
         merged, _, idx = ref.merge_texts(texts, n)
         out['reference_outputs']['merge_texts'].append([texts, n, merged, idx])
+    # (texts, max_length, max_overlap, max_overlap_len) -> chunks, indices
+    out['reference_outputs']['merge_texts_overlap'] = []
+    parts = ['One.', 'Two two.', 'Three three three.', 'Four.', 'Five five.', 'Six six six six.', 'Seven.']
+    for n, ov, ovl in ((24, 1, 0.5), (30, 2, 0.5), (30, 2, 6), (40, 3, 0.2), (18, 1, 0.9)):
+        merged, _, idx = ref.merge_texts(parts, n, ov, ovl)
+        out['reference_outputs']['merge_texts_overlap'].append([parts, n, ov, ovl, merged, idx])
     # the reference's own expectations must hold for its own function (sanity of the transcription)
     for text, n in REFERENCE_TESTS['split_sentences']:
         assert len(ref.split_sentences(text)) == n, (text, ref.split_sentences(text))

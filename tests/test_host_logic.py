@@ -110,7 +110,8 @@ def test_tacotron2_infer_gives_up_after_max_trial_and_splits():
     synth = FakeSynth([5, 5, 5, 5, 5, 5, 5])
     out = Tacotron2(synth).infer('Short one. Another short sentence here.', max_text_length=-2, max_trial=2)
     assert len(synth.calls) == 4                                # 2 sentences x max_trial
-    assert out['splitted'] == ['short one.', 'another short sentence here.']
+    # sentences keep the space behind their terminator (split_sentences) and the cleaners collapse but do not strip it
+    assert out['splitted'] == ['short one. ', 'another short sentence here.']
     assert 'audio' not in out and len(out['mel']) == 2
 
 
@@ -259,8 +260,10 @@ def test_text_normalisation_known_answers():
     assert en('1,234,567') == 'one million, two hundred and thirty-four thousand, five hundred and sixty-seven'
     assert en('3.14') == 'three punt fourteen' and en('0.05') == 'zero punt zero five'      # (sic) 'punt', numbers.py:18-20
     assert en('100% & more') == 'one hundred percent and more'
-    assert en('-5 + 3 = -2') == 'minus five plus three equal minus two'
-    assert en('**bold** £20 naïve café') == 'bold twenty pounds naive cafe'
+    assert en('-5 + 3 = -2') == ' minus five plus three equal minus two'      # leading space kept (test_utils_text.py:52)
+    # (sic) English text is not ASCII-folded by the reference (cleaners.py:336 assigns the result to `lang`)
+    assert en('**bold** £20 naïve café') == 'bold twenty pounds naïve café'
+    assert en('**bold** £20 naïve café', convert_to_ascii=True) == 'bold twenty pounds naive cafe'
     assert en('$1') == 'one dollar' and en('$0.01') == 'one cent' and en('10-5') == 'ten - five'
     assert [ordinal_to_words(n) for n in (1, 2, 3, 5, 12, 20, 21, 100, 101)] == [
         'first', 'second', 'third', 'fifth', 'twelfth', 'twentieth', 'twenty-first', 'one hundredth',

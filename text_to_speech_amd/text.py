@@ -41,7 +41,7 @@ _abbrev_re = {'en': re.compile(r'\b(%s)(\.|\b)' % '|'.join(sorted(_abbreviations
 
 
 def expand_abbreviations(text: str, lang: str = 'en') -> str:
-    regex = _abbrev_re.get(lang)
+    regex = _abbrev_re.get(_tables_lang(lang) if lang == 'be' else lang)
     if regex is None:
         return text
     return regex.sub(lambda m: _abbreviations_en[m.group(1).lower()], text)
@@ -141,12 +141,46 @@ def ordinal_to_words_fr(n: int) -> str:
     return w + 'ième'
 
 
+# Belgian French (lang 'be'): the reference rewrites num2words' French output (numbers.py:101-131): "soixante-dix…" becomes
+# "septante …" and "quatre-vingt-dix…" "nonante …" -- with a SPACE before the unit ("septante deux", "nonante et un").
+# Same rewriting here on the output of the French speller: (French teen stem, Belgian unit stem), longest stems first.
+_BE_TENS = (('soixante-', 'septante'), ('quatre-vingt-', 'nonante'))
+_BE_TEENS_CARDINAL = (('onze', ' et un'), ('douze', ' deux'), ('treize', ' trois'), ('quatorze', ' quatre'),
+                      ('quinze', ' cinq'), ('seize', ' six'), ('dix-sept', ' sept'), ('dix-huit', ' huit'),
+                      ('dix-neuf', ' neuf'), ('dix', ''))
+_BE_TEENS_ORDINAL = (('onz', ' et un'), ('douz', ' deux'), ('treiz', ' trois'), ('quatorz', ' quatre'),
+                     ('quinz', ' cinqu'), ('seiz', ' six'), ('dix-sept', ' sept'), ('dix-huit', ' huit'),
+                     ('dix-neuv', ' neuv'))
+
+
+def _to_belgian(words: str, ordinal: bool) -> str:
+    for prefix, new in _BE_TENS:
+        if prefix not in words:
+            continue
+        for teen, unit in (_BE_TEENS_ORDINAL if ordinal else _BE_TEENS_CARDINAL):
+            words = words.replace(prefix + teen, new + unit)
+        if ordinal:
+            words = words.replace(prefix + 'dix', new[:-1])       # "soixante-dixième" -> "septantième"
+    return words
+
+
 def _cardinal(n, lang):
-    return number_to_words(int(n)) if lang == 'en' else number_to_words_fr(int(n))
+    if lang == 'en':
+        return number_to_words(int(n))
+    words = number_to_words_fr(int(n))
+    return _to_belgian(words, False) if lang == 'be' else words
 
 
 def _ordinal(n, lang):
-    return ordinal_to_words(int(n)) if lang == 'en' else ordinal_to_words_fr(int(n))
+    if lang == 'en':
+        return ordinal_to_words(int(n))
+    words = ordinal_to_words_fr(int(n))
+    return _to_belgian(words, True) if lang == 'be' else words
+
+
+def _tables_lang(lang):
+    """'be' shares every word table with 'fr' (numbers.py:22-35 repeats the French entries under 'be')."""
+    return 'fr' if lang == 'be' else lang
 
 
 # tables of numbers.py:18-75
@@ -184,6 +218,7 @@ _ordinal_re = re.compile(r'([0-9]+)(st|nd|rd|th|er|ère|ème|eme|ième|ieme)')
 
 
 def _expand_units(m, lang):
+    lang = _tables_lang(lang)                                   # numbers.py:137 maps 'be' to 'fr' here
     n, prefix, unit, per_time = m.groups()
     if n == '1' and lang == 'fr' and unit == 't':
         n = 'une'
@@ -200,13 +235,13 @@ def _expand_hms(parts, lang):
     for t, unit in parts:
         if t is None:
             continue
-        word = _time_words[unit][lang]
+        word = _time_words[unit][_tables_lang(lang)]
         if int(t) > 1:
             word += 's'
-        elif lang == 'fr' and int(t) == 1:
+        elif lang == 'fr' and int(t) == 1:                      # (sic) not for 'be': "1 sec" -> "un seconde" there
             t = 'une'
         out.append('{} {}'.format(t, word))
-    return _time_sep[lang].join(out)
+    return _time_sep[_tables_lang(lang)].join(out)
 
 
 def _expand_time(m, lang):
@@ -236,7 +271,7 @@ def _extend_with_zeros(text, lang):
         return words
     if n < 4:
         return ' '.join([_cardinal(0, lang)] * n + [words])
-    return '{} {} {} {}'.format(_cardinal(n, lang), _math_words['*'][lang], _cardinal(0, lang), words)
+    return '{} {} {} {}'.format(_cardinal(n, lang), _math_words['*'][_tables_lang(lang)], _cardinal(0, lang), words)
 
 
 def _expand_number(m, lang):
@@ -246,14 +281,15 @@ def _expand_number(m, lang):
     ent, dec = num.split('.')
     if dec.count('0') == len(dec):
         return _cardinal(ent, lang)
-    return '{} {} {}'.format(_cardinal(ent, lang), _comma_word[lang], _extend_with_zeros(dec, lang))
+    return '{} {} {}'.format(_cardinal(ent, lang), _comma_word.get(lang, ''), _extend_with_zeros(dec, lang))   # no 'be' entry
 
 
 def normalize_numbers(text: str, lang: str = 'en', expand_symbols: bool = True) -> str:
     """Restatement of numbers.py:249-271, same order of substitutions."""
     if expand_symbols:
         text = _units_re.sub(lambda m: _expand_units(m, lang), text)
-        text = _math_symbol_re.sub(lambda m: ' ' + ' '.join(_math_words[s][lang] for s in m.group(0).split()) + ' ', text)
+        text = _math_symbol_re.sub(lambda m: ' ' + ' '.join(_math_words[s][_tables_lang(lang)]
+                                                            for s in m.group(0).split()) + ' ', text)
     text = _time_re.sub(lambda m: _expand_time(m, lang), text)
     text = _clock_re.sub(lambda m: _expand_hms(zip(m.groups(), ('h', 'min', 'sec')), lang), text)
     text = _comma_number_re.sub(lambda m: m.group(1).replace(',', '.') if lang == 'fr' and m.group(1).count(',') == 1
@@ -275,6 +311,7 @@ _special_symbols = {'=': {'fr': 'égal', 'en': 'equal'}, '+': {'fr': 'plus', 'en
 
 
 def expand_special_symbols(text: str, lang: str) -> str:
+    lang = _tables_lang(lang)
     for symbol, words in _special_symbols.items():
         text = text.replace(symbol, ' ' + words[lang] + ' ')
     return text
@@ -325,8 +362,12 @@ def collapse_repetitions(text: str, max_repetition: int) -> str:
 
 def complete_cleaners(text: str, lang: str, *, to_lowercase=True, to_expand=True, to_expand_abrev=True,
                       to_expand_symbols=True, to_expand_acronyms=False, replacements=None, patterns=None,
-                      max_repetition=-1, **_) -> str:
-    """Restatement of cleaners.py:296-342, same order of steps."""
+                      max_repetition=-1, convert_to_ascii=None, **_) -> str:
+    """Restatement of cleaners.py:296-342, same order of steps and the same result, including two quirks of that code:
+    the English branch assigns the ASCII-folded text to `lang` instead of `text` (cleaners.py:336), so English text is NOT
+    folded (an 'é' later falls out of the vocabulary instead of becoming 'e'), and white space is collapsed but not
+    stripped (the tokenizer strips, or not, per its `lstrip` / `rstrip`).  `convert_to_ascii=True` opts into the folding
+    the reference evidently intended; `to_expand_acronyms` (accepted but unused by the reference) spells acronyms here."""
     if patterns:
         for pattern, repl in patterns.items():
             text = re.sub(pattern, repl, text)
@@ -342,18 +383,18 @@ def complete_cleaners(text: str, lang: str, *, to_lowercase=True, to_expand=True
         text = re.sub(r'\*\*(.*)\*\*', r'\1', text)                           # remove_markdown
         if to_expand_abrev:
             text = expand_abbreviations(text, lang)
-        text = normalize_numbers(text, lang if lang != 'be' else 'fr', expand_symbols=to_expand_symbols)
+        text = normalize_numbers(text, lang, expand_symbols=to_expand_symbols)
         if to_expand_symbols:
-            text = expand_special_symbols(text, lang if lang != 'be' else 'fr')
+            text = expand_special_symbols(text, lang)
     if lang in ('fr', 'be'):
         text = re.sub(r'(ï)', 'hi', re.sub('(aï)\b', 'aille', text))               # expand_tremas (sic: '\b' is a backspace there)
         keep = set(_accents_kept)
         text = ''.join(c if c in keep else _to_ascii(c) for c in text)
-    else:
+    elif convert_to_ascii:
         text = _to_ascii(text)
     if max_repetition > 1:
         text = collapse_repetitions(text, max_repetition)
-    return re.sub(r'\s+', ' ', text).strip()
+    return re.sub(r'\s+', ' ', text)
 
 
 _accents_kept = 'âéèêîç'                                            # cleaners.py:52
@@ -367,39 +408,165 @@ def french_cleaners(text: str, **kwargs) -> str:
     return complete_cleaners(text, 'fr', **kwargs)
 
 
-def split_sentences(text: str):
-    parts = re.split(r'(?<=[.!?])\s+', text.strip())
-    return [p for p in parts if p]
+def belgian_cleaners(text: str, **kwargs) -> str:
+    return complete_cleaners(text, 'be', **kwargs)
 
 
-def split_text(text: str, max_length: int):
-    """Greedy sentence packing up to `max_length` characters (text_processing.py:34)."""
-    out, cur = [], ''
-    for sent in split_sentences(text):
-        while len(sent) > max_length:                       # overlong sentence: cut at the last space
-            cut = sent.rfind(' ', 0, max_length)
-            cut = cut if cut > 0 else max_length
-            if cur:
-                out.append(cur)
-                cur = ''
-            out.append(sent[:cut].strip())
-            sent = sent[cut:].strip()
-        if cur and len(cur) + 1 + len(sent) > max_length:
-            out.append(cur)
-            cur = sent
-        else:
-            cur = (cur + ' ' + sent).strip()
-    if cur:
-        out.append(cur)
+# ---- sentence / chunk splitting (behaviour of utils/text/text_processing.py:20-31, :34-143, :145-226, :228-279, :388-391;
+#      pinned by tests/golden/text_vectors.json: the reference's own test cases plus outputs of the reference functions) ----
+# A sentence ends at: a blank line; an ellipsis, '?' or '!' (with the spaces that follow); a dot followed by white space
+# unless the dot closes a one-letter abbreviation ("e.g.", "M.H.C.P."); a line break in front of a list marker, a digit or
+# a capital.  Terminators stay attached to the sentence they end.
+EOS_RULES = (
+    '\n\n',
+    r'\.\.\.\s*', r'\?\s*', r'\!\s*',
+    r'(?<!\.[a-zA-Z]{1})\.\s+',
+    r'\n(?=\s*[-\*\dA-Z])',
+)
+# second level (inside an overlong sentence): a comma not inside a number, a colon, a parenthesised group
+SUBSENTENCE_RULES = (r',(?!\d)', ': ', r'\(.*\)')
+_OPENER_OF = {')': '(', ']': '[', '}': '{', '"': '"', "'": "'", '`': '`'}
+
+
+def _compile_rules(rules):
+    if isinstance(rules, str):
+        rules = (rules,)
+    return re.compile('|'.join(r if '\\' in r else re.escape(r) for r in rules))     # plain strings are literals
+
+
+def _bodies_and_separators(text, regex):
+    """[(body, separator)]: the text between two matches and the match that follows it (None after the last body)."""
+    out, pos = [], 0
+    for m in regex.finditer(text):
+        if m.end() == m.start():
+            continue                                            # (no rule can match empty; guard against user patterns)
+        out.append((text[pos:m.start()], m.group(0)))
+        pos = m.end()
+    out.append((text[pos:], None))
     return out
 
 
+def _only_closes_what_was_opened(previous, body):
+    """True if the first word of `body` consists of closing quotes / brackets whose openers occur in `previous`: the
+    terminator sat inside a quotation (`She said "Hello !"`), so `body` still belongs to the previous sentence."""
+    words = body.split()
+    return bool(words) and all(c in _OPENER_OF and _OPENER_OF[c] in previous for c in words[0])
+
+
+def split_sentences(text: str, eos_pattern=EOS_RULES, strip: bool = False):
+    """`text` -> list of sentences, each keeping its terminator and the white space behind it (`strip` removes the
+    spaces, not the newlines).  Numbered headings ("1. First item", "1.2.3. Title") stay in one piece."""
+    segments = _bodies_and_separators(text.strip(), _compile_rules(eos_pattern))
+    sentences, k = [], 0
+    while k < len(segments):
+        body = segments[k][0]
+        if sentences and _only_closes_what_was_opened(sentences[-1], body):
+            sentences[-1] += body
+        elif body.strip():
+            # an all-digit body in front of a dot is an enumeration marker: glue what follows (repeatedly: "1. 2. text")
+            while k + 1 < len(segments) and segments[k][0].isdigit() and segments[k][1].strip() == '.':
+                body += segments[k][1] + segments[k + 1][0]
+                k += 1
+            sentences.append(body)
+        separator = segments[k][1]
+        if separator is not None and sentences:
+            sentences[-1] += separator
+        k += 1
+    return [s.strip(' ') for s in sentences] if strip else sentences
+
+
+def merge_texts(texts, max_length, max_overlap=0, max_overlap_len=0.2, *, tokens=None, tokenizer=None, **_):
+    """Greedy packing of consecutive parts into chunks of at most `max_length` tokens (characters by default); parts are
+    stripped of spaces and joined by one space.  `max_overlap` > 0 repeats up to that many trailing parts of the previous
+    chunk (at most `max_overlap_len` tokens) at the start of the next.  Returns (chunks, chunk tokens, part indices)."""
+    if isinstance(max_overlap_len, float):
+        max_overlap_len = int(max_overlap_len * max_length)
+    if tokenizer is None:
+        tokenizer = list
+    elif hasattr(tokenizer, 'tokenize'):
+        tokenizer = tokenizer.tokenize
+    if tokens is None:
+        tokens = [tokenizer(t) for t in texts]
+    texts = [t.strip(' ') for t in texts]
+    groups, size = [], 0                                          # group = list of part indices
+    for i, tok in enumerate(tokens):
+        if groups and size + len(tok) <= max_length:
+            groups[-1].append(i)
+            size += len(tok)
+            continue
+        group, size = [i], len(tok)
+        if groups and max_overlap > 0 and len(tok) < max_length:
+            budget, used = min(max_overlap_len, max_length - len(tok)), 0
+            for j in reversed(groups[-1][-max_overlap:]):
+                if used + len(tokens[j]) > budget:
+                    break
+                group.insert(0, j)
+                used += len(tokens[j])
+            size += used
+        groups.append(group)
+    chunks = [' '.join(texts[i] for i in g) for g in groups]
+    chunk_tokens = [[tk for i in g for tk in tokens[i]] for g in groups]
+    return chunks, chunk_tokens, groups
+
+
+def split_text(text: str, max_length: int, *, tokens=None, tokenizer=None, eos_pattern=EOS_RULES,
+               sent_pattern=SUBSENTENCE_RULES, tolerance=0, sent_tolerance=0, merge=True, err_mode='skip',
+               return_tokens=False, **kwargs):
+    """Chunks of at most `max_length` tokens (characters by default), cut at the coarsest boundary that fits: sentences
+    first, then sub-sentences (commas, colons, parentheses), then words; consecutive pieces are merged back up to the
+    limit.  Like the reference, the first sentence is kept whole whatever its length, and a single word that is still
+    too long is dropped with a warning (`err_mode`: 'skip' | 'ignore' | 'keep' | 'error')."""
+    if tokenizer is None:
+        tokenizer = list
+    elif hasattr(tokenizer, 'tokenize'):
+        tokenizer = tokenizer.tokenize
+    if isinstance(tolerance, float):
+        tolerance = int(tolerance * max_length)
+    if isinstance(sent_tolerance, float):
+        sent_tolerance = int(sent_tolerance * max_length)
+    text_limit, sent_limit = max_length + tolerance, max_length + sent_tolerance
+    if tokens is None:
+        tokens = tokenizer(text)
+    if len(tokens) <= text_limit:
+        return ([text], [tokens]) if return_tokens else [text]
+
+    pieces = split_sentences(text, eos_pattern, strip=False)
+    piece_tokens = [tokenizer(p) for p in pieces]
+    out_text, out_tokens = pieces[:1], piece_tokens[:1]
+    for piece, tok in zip(pieces[1:], piece_tokens[1:]):
+        if len(tok) <= sent_limit:
+            out_text.append(piece)
+            out_tokens.append(tok)
+        elif sent_pattern:
+            finer = ' ' if sent_pattern != ' ' else None            # sub-sentences -> words -> give up
+            sub_text, sub_tokens = split_text(piece, sent_limit, tokens=tok, tokenizer=tokenizer, eos_pattern=sent_pattern,
+                                              sent_pattern=finer, err_mode=err_mode, return_tokens=True)
+            out_text.extend(sub_text)
+            out_tokens.extend(sub_tokens)
+        elif err_mode == 'error':
+            raise RuntimeError('It was not possible to split `{}`'.format(piece))
+        elif err_mode == 'keep':
+            out_text.append(piece)
+            out_tokens.append(tok)
+        elif err_mode == 'skip':
+            import warnings
+            warnings.warn('The text `{}` is skipped as it is too long'.format(piece))
+    if merge:
+        out_text, out_tokens, _ = merge_texts(out_text, text_limit, tokens=out_tokens, tokenizer=tokenizer, **kwargs)
+    return (out_text, out_tokens) if return_tokens else out_text
+
+
 class CharTokenizer:
-    def __init__(self, lang='en'):
+    """Character tokenizer of the TTS models (utils/text/tokenizer.py:53, :345-352, :394): cleaners, then one id per
+    character of the symbol table (unknown characters are dropped).  `lstrip` / `rstrip` default to False like the
+    reference's `Tokenizer`, so a sentence keeps the space that `split_sentences` leaves behind its terminator."""
+
+    def __init__(self, lang='en', lstrip=False, rstrip=False):
         self.lang = lang
+        self.lstrip, self.rstrip = lstrip, rstrip
         self.symbols = en_symbols if lang == 'en' else fr_symbols
         self.index = {s: i for i, s in enumerate(self.symbols)}
-        self.cleaner = english_cleaners if lang == 'en' else french_cleaners
+        self.cleaner = {'en': english_cleaners, 'fr': french_cleaners, 'be': belgian_cleaners}.get(lang, french_cleaners)
 
     @property
     def vocab_size(self):
@@ -407,8 +574,13 @@ class CharTokenizer:
 
     def clean_text(self, text, **kwargs):
         allowed = ('to_lowercase', 'to_expand', 'to_expand_abrev', 'to_expand_symbols', 'to_expand_acronyms',
-                   'replacements', 'patterns', 'max_repetition')
-        return self.cleaner(text, **{k: v for k, v in kwargs.items() if k in allowed})
+                   'replacements', 'patterns', 'max_repetition', 'convert_to_ascii')
+        text = self.cleaner(text, **{k: v for k, v in kwargs.items() if k in allowed})
+        if self.lstrip:
+            text = text.lstrip()
+        if self.rstrip:
+            text = text.rstrip()
+        return text
 
     def encode(self, text, cleaned=False):
         if not cleaned:
