@@ -137,8 +137,9 @@ def attention(query, memory, processed_memory, prev_w, cum_w, mask, w):
 
 
 def decode(memory, mask, w, cfg, max_length, early_stopping=True, prenet_masks=None,
-           attn_mask_win_len=None, attn_mask_offset=None):
-    """Tacotron2Decoder.infer.  tacotron2_arch.py:609-749."""
+           attn_mask_win_len=None, attn_mask_offset=None, trace=None):
+    """Tacotron2Decoder.infer.  tacotron2_arch.py:609-749.  `trace` (a dict, tests only) receives 'cell_out'
+    [B, steps, 1024 + enc]: the projection / gate input of every step (tests script stop tokens from it)."""
     dt = memory.dtype
     B, Tin, enc = memory.shape
     d = 'tacotron2/decoder'
@@ -178,6 +179,8 @@ def decode(memory, mask, w, cfg, max_length, early_stopping=True, prenet_masks=N
                                  w[f'{d}/decoder_rnn/cell_0/kernel'], w[f'{d}/decoder_rnn/cell_0/recurrent_kernel'],
                                  w[f'{d}/decoder_rnn/cell_0/bias'])
         cell_out = np.concatenate([h_dec, ctx], -1)
+        if trace is not None:
+            trace.setdefault('cell_out', []).append(cell_out.copy())
         frame = cell_out @ w[f'{d}/linear_projection/kernel'] + w[f'{d}/linear_projection/bias']
         stop = _sigmoid(cell_out @ w[f'{d}/gate_output/kernel'] + w[f'{d}/gate_output/bias'])[:, 0]
         finished = finished | (stop > 0.5)                      # :664
@@ -188,6 +191,8 @@ def decode(memory, mask, w, cfg, max_length, early_stopping=True, prenet_masks=N
         main_attention = prev_w.argmax(axis=1)
         t += 1
     dec_mask = np.arange(max_length)[None] <= lengths[:, None]  # :745, per-row (see docstring)
+    if trace is not None and 'cell_out' in trace:
+        trace['cell_out'] = np.stack(trace['cell_out'], axis=1)
     return outputs, stop_tokens, dec_mask, attn, lengths, t
 
 
@@ -208,7 +213,7 @@ def resolve_max_length(mask, max_length):
 
 
 def infer(tokens, w, cfg, speaker_embedding=None, max_length=10.0, early_stopping=True, prenet_masks=None,
-          attn_mask_win_len=None, attn_mask_offset=0.5, dtype=np.float32):
+          attn_mask_win_len=None, attn_mask_offset=0.5, dtype=np.float32, trace=None):
     """Tacotron2.infer.  tacotron2_arch.py:866-925."""
     w = {k: v.astype(dtype) for k, v in w.items() if k.startswith('tacotron2/')}
     tokens = np.asarray(tokens, dtype=np.int32)
@@ -219,7 +224,7 @@ def infer(tokens, w, cfg, speaker_embedding=None, max_length=10.0, early_stoppin
     if prenet_masks is not None:
         prenet_masks = np.asarray(prenet_masks, dtype=dtype)
     dec_out, stop_tokens, dec_mask, attn, lengths, _ = decode(
-        memory, mask, w, cfg, max_length, early_stopping, prenet_masks, attn_mask_win_len, attn_mask_offset)
+        memory, mask, w, cfg, max_length, early_stopping, prenet_masks, attn_mask_win_len, attn_mask_offset, trace)
     post = postnet(dec_out, dec_mask, w, cfg)
     mel = dec_out + post
     return Tacotron2InferenceOutput(decoder_output=dec_out, mel=mel, stop_tokens=stop_tokens,

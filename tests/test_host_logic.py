@@ -334,3 +334,57 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from text_to_speech_amd import _lib
     with pytest.raises(_lib.HipLibraryError, match='no CPU fallback'):
         _lib.load_library(str(tmp_path / 'nope.so'))
+
+
+# ------------------------------------------------------------------ SV2TTS wrapper (models/tts/sv2tts_tacotron2.py:103-128)
+def test_select_embedding_modes():
+    import pandas as pd
+    from text_to_speech_amd.tacotron2 import select_embedding
+    pool = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert np.array_equal(select_embedding(pool, 1), pool[1])
+    for m in ('mean', 'avg', 'average'):
+        np.testing.assert_allclose(select_embedding(pool, m), pool.mean(0))
+    assert any(np.array_equal(select_embedding(pool, 'random'), r) for r in pool)
+    assert np.array_equal(select_embedding(pool, lambda e: e[-1] * 2), pool[-1] * 2)
+    assert np.array_equal(select_embedding(pool[0], 0), pool[0])             # a 1-D array is a collection of one
+    with pytest.raises(ValueError, match='Unknown embedding selection mode'):
+        select_embedding(pool, 'median')
+    df = pd.DataFrame({'id': ['a', 'b', 'a'], 'embedding': list(pool)})
+    np.testing.assert_allclose(select_embedding(df, 'mean', id='a'), pool[[0, 2]].mean(0))
+    np.testing.assert_allclose(select_embedding(df, 'mean', id='zzz'), pool.mean(0))     # no match: filter dropped
+    assert np.array_equal(select_embedding(df, 1), pool[1])
+
+
+def test_sv2tts_infer_resolves_the_speaker_embedding():
+    from text_to_speech_amd.tacotron2 import SV2TTSTacotron2
+    pool = np.random.default_rng(0).standard_normal((3, 256)).astype(np.float32)
+    synth = FakeSynth([], default=100)
+    model = SV2TTSTacotron2(synth, lang='fr', embeddings=pool, use_label_embedding=True)
+    text = 'Bonjour à tous, ceci est un test.'
+
+    # the runtime receives (tokens [1, Tin], embedding [1, 256]); FakeSynth records only the tokens, so spy on the call
+    seen = []
+
+    class Spy(FakeSynth):
+        def __call__(self, inputs, **kw):
+            seen.append(inputs)
+            return FakeSynth.__call__(self, inputs, **kw)
+    spy = Spy([], default=100)
+    model.compiled_infer = spy
+    model.infer(text)                                                # default selector 0 -> first row
+    assert isinstance(seen[-1], tuple) and seen[-1][0].shape[0] == 1 and np.array_equal(seen[-1][1], pool[:1])
+    model.infer(text, embeddings=2)
+    assert np.array_equal(seen[-1][1][0], pool[2])
+    model.infer(text, embeddings=None)                               # use_label_embedding -> mean
+    np.testing.assert_allclose(seen[-1][1][0], pool.mean(0), rtol=1e-6)
+    model.infer(text, embeddings='mean')
+    np.testing.assert_allclose(seen[-1][1][0], pool.mean(0), rtol=1e-6)
+    model.infer(text, embeddings={'mode': 1})
+    assert np.array_equal(seen[-1][1][0], pool[1])
+    vec = np.ones(256, np.float32)
+    model.infer(text, embeddings=vec)                                # an explicit vector passes through
+    assert np.array_equal(seen[-1][1][0], vec)
+    with pytest.raises(ValueError, match='shape'):
+        model.infer(text, embeddings={'mode': lambda e: e[0][:8]})      # a selector that yields the wrong width
+    with pytest.raises(ValueError, match='no speaker embeddings'):
+        SV2TTSTacotron2(spy, lang='fr').infer(text)

@@ -82,51 +82,70 @@ class Callback:
         pass
 
 
+class NumberedPath:
+    """File-name pattern with an optional running number: `audio-{}.wav`, `mel-{i}.npy`, `part-{:02d}.wav`, and named
+    fields taken from the result (`{basename}` = the stem of the entry's `filename`).  The first number is the count of
+    files already matching the pattern on disk (so numbering continues across runs), unless the result itself carries
+    the number under `index_key`."""
+
+    def __init__(self, pattern, first=-1, index_key=None):
+        self.pattern = pattern
+        self.numbered = _INDEX_RE.search(pattern) is not None
+        self.next_number = first
+        self.index_key = index_key
+
+    @property
+    def directory(self):
+        return os.path.dirname(self.pattern)
+
+    def _take_number(self, output):
+        if not self.numbered:
+            return -1
+        if self.index_key in output:
+            return output[self.index_key]
+        if self.next_number == -1:
+            self.next_number = len(glob.glob(_INDEX_RE.sub('*', self.pattern)))
+        self.next_number += 1
+        return self.next_number - 1
+
+    def make(self, infos, output):
+        number = self._take_number(output)
+        fields = {k: v for k, v in output.items() if k != 'i' and isinstance(v, (str, int, float))}
+        if '{basename}' in self.pattern and 'basename' not in fields:
+            fields['basename'] = os.path.basename(infos['filename']).rpartition('.')[0]
+        return self.pattern.format(number, i=number, **fields)
+
+
 class FileSaver(Callback):
+    """Writes `output[data_key]` to a file and records the file name in the entry under `key`.  An entry that already has a
+    file name keeps it (a re-synthesized text overwrites its own file); a result whose value already is a file name is only
+    recorded.  `save_fn(filename, data, **{k: output[k] for k in additional_keys})` does the writing."""
+
     def __init__(self, key, file_format, *, data_key=None, additional_keys=None, index=-1, index_key=None,
                  save_fn=None, name=None, **kwargs):
         super().__init__(name=name or 'saving {}'.format(key), **kwargs)
         self.key = key
         self.data_key = data_key or key
-        self.file_format = file_format
-        self.additional_keys = additional_keys or []
-        self.index = index
-        self.index_key = index_key
-        self.use_index = _INDEX_RE.search(file_format) is not None
+        self.path = NumberedPath(file_format, first=index, index_key=index_key)
+        self.additional_keys = list(additional_keys or [])
         self.save_fn = save_fn
+
+    @property
+    def file_format(self):
+        return self.path.pattern
 
     def build(self):
         super().build()
-        directory = os.path.dirname(self.file_format)
-        if directory:
-            os.makedirs(directory, exist_ok=True)
-
-    def _get_index(self, output):
-        if not self.use_index:
-            return -1
-        if self.index_key in output:
-            return output[self.index_key]
-        if self.index == -1:
-            self.index = len(glob.glob(_INDEX_RE.sub('*', self.file_format)))
-        idx = self.index
-        self.index += 1
-        return idx
-
-    def _format_filename(self, infos, output):
-        idx = self._get_index(output)
-        fields = {k: v for k, v in output.items() if isinstance(v, (str, int, float))}
-        if '{basename}' in self.file_format and 'basename' not in fields:
-            fields['basename'] = '.'.join(os.path.basename(infos['filename']).split('.')[:-1])
-        fields.pop('i', None)
-        return self.file_format.format(idx, i=idx, **fields)
+        if self.path.directory:
+            os.makedirs(self.path.directory, exist_ok=True)
 
     def apply(self, infos, output, **_):
-        if isinstance(output.get(self.key, None), str):       # already a file name: just remember it
-            if self.key not in infos:
-                infos[self.key] = output[self.key]
+        value = output.get(self.key, None)
+        if isinstance(value, str):
+            infos.setdefault(self.key, value)
             return None
         if infos.get(self.key, None) is None:
-            infos[self.key] = self._format_filename(infos, output)
+            infos[self.key] = self.path.make(infos, output)
         self.save(infos[self.key], output[self.data_key], **{k: output[k] for k in self.additional_keys})
         return infos[self.key]
 

@@ -26,7 +26,9 @@ class TTSPipeline:
         import torch
         eng = self.engine
         dev = torch.device('cuda', eng.device)
-        tok = torch.as_tensor(np.asarray(tokens), dtype=torch.int32).to(dev)
+        as_dev = lambda x, dt: (x.to(device=dev, dtype=dt) if torch.is_tensor(x)
+                                else torch.as_tensor(np.asarray(x), dtype=dt).to(dev))
+        tok = as_dev(tokens, torch.int32)
         B = int(tok.shape[0])
         n_tok = int((tok != 0).sum(dim=1).max())
         max_len = int(np.float32(n_tok) * np.float32(max_length)) if isinstance(max_length, float) else int(max_length)
@@ -35,9 +37,9 @@ class TTSPipeline:
             from .runtime import sample_prenet_masks
             prenet_masks = sample_prenet_masks(self._rng, B, max_len)
         if prenet_masks is not None:
-            prenet_masks = torch.as_tensor(prenet_masks, dtype=torch.float32).to(dev)
+            prenet_masks = as_dev(prenet_masks, torch.float32)
         if speaker is not None:
-            speaker = torch.as_tensor(np.asarray(speaker), dtype=torch.float32).to(dev)
+            speaker = as_dev(speaker, torch.float32)
         out = eng.tacotron2_infer(tok, speaker=speaker, max_len=max_len, early_stopping=early_stopping,
                                   prenet_masks=prenet_masks, want_attention=False,
                                   precision=self.synthesizer_precision)
@@ -54,8 +56,20 @@ class TTSPipeline:
         if z is None and not deterministic:
             z = torch.from_numpy(self._rng.standard_normal((B, T * 32, 8)).astype(np.float32)).to(dev)
         elif z is not None:
-            z = torch.as_tensor(z, dtype=torch.float32).to(dev)[:, :T * 32]
+            z = as_dev(z, torch.float32)[:, :T * 32]
         audio = eng.waveglow_infer(mel.contiguous(), z=z, sigma=sigma, precision=self.vocoder_precision)
         audio_h = audio.cpu().numpy()
         n = lengths.cpu().numpy()
         return [audio_h[b, :int(n[b]) * 256].copy() for b in range(B)], n, steps
+
+    def shard_fn(self, **kwargs):
+        """`synth_fn(local_tokens, local_speaker) -> (audio [n, S] zero padded, sample counts [n])` for
+        `distributed.synthesize_sharded`: this rank's share of the utterances through `synthesize_tokens(**kwargs)`."""
+        def synth(local_tokens, local_speaker):
+            audios, n_frames, _ = self.synthesize_tokens(local_tokens, speaker=local_speaker, **kwargs)
+            counts = np.asarray([len(a) for a in audios], dtype=np.int64)
+            padded = np.zeros((len(audios), max(1, int(counts.max()) if len(audios) else 1)), np.float32)
+            for i, a in enumerate(audios):
+                padded[i, :len(a)] = a
+            return padded, counts
+        return synth

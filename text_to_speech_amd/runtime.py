@@ -18,6 +18,7 @@ or `deterministic=True`, or a `seed` for the documented numpy generator (`sample
 from __future__ import annotations
 
 import os
+import threading
 from abc import ABCMeta, abstractmethod
 
 import numpy as np
@@ -36,28 +37,40 @@ def sample_prenet_masks(rng, B, max_len):
 
 
 class Runtime(metaclass=ABCMeta):
-    """Same shape as the reference's `Runtime`: engines are cached per `path` in a class-level dict."""
+    """Plug-in interface of the reference's execution seam (utils/keras/runtimes/runtime.py:19-41): constructed as
+    `cls(path, **kwargs)` by `build_runtime`, called in place of `model.infer`, with the loaded engine shared between
+    instances.  Two deliberate differences from the reference's class: the shared-engine table is keyed by everything that
+    changes what gets loaded -- (class, path, device, speaker_embedding_dim), not the path alone, so `device=1` or another
+    speaker width never silently returns the first engine -- and it is guarded by a lock (the reference's dict is not)."""
     _engines = {}
+    _engines_lock = threading.Lock()
+
+    @classmethod
+    def _engine_key(cls, path, kwargs):
+        return (cls.__name__, str(path), int(kwargs.get('device', 0) or 0), int(kwargs.get('speaker_embedding_dim', 0) or 0))
 
     def __init__(self, path, *, engine=None, reload=False, **kwargs):
-        if engine is None:
-            if path not in self._engines or reload:
-                self._engines[path] = self.load_engine(path, **kwargs)
-            engine = self._engines[path]
         self.path = path
-        self.engine = engine
+        if engine is not None:
+            self.engine = engine
+            return
+        key = self._engine_key(path, kwargs)
+        with Runtime._engines_lock:
+            if reload or key not in Runtime._engines:
+                Runtime._engines[key] = self.load_engine(path, **kwargs)
+            self.engine = Runtime._engines[key]
 
     def __repr__(self):
-        return '<{} path={}>'.format(self.__class__.__name__, self.path)
+        return f'<{type(self).__name__} path={self.path}>'
 
     @abstractmethod
     def __call__(self, *args, **kwargs):
-        """Performs custom runtime inference."""
+        """Runs inference on the engine."""
 
     @staticmethod
     @abstractmethod
     def load_engine(path, **kwargs):
-        """Loads the custom runtime engine."""
+        """Builds the engine for `path`."""
 
 
 class HipRuntime(Runtime):

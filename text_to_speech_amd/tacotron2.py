@@ -278,6 +278,83 @@ class Tacotron2:
         return self.predict(_iterate(stream), vocoder=vocoder, **kwargs)
 
 
+# ---- multi-speaker wrapper (models/tts/sv2tts_tacotron2.py:18-128, utils/embeddings.py:249-286) --------------------------
+def select_embedding(embeddings, mode='random', **filters):
+    """One speaker embedding (1-D) out of a collection: a 2-D array, a 1-D array (a collection of one) or a pandas
+    DataFrame with an 'embedding' column (then `filters` on other columns narrow the choice; no match = no filter, with a
+    warning).  mode: an int (row), 'mean' / 'avg' / 'average', 'random' (Python's `random`, like the reference) or a
+    callable taking the [n, E] array."""
+    import random
+    if hasattr(embeddings, 'columns'):
+        rows = embeddings
+        used = {k: v for k, v in filters.items() if k in embeddings.columns}
+        if used:
+            keep = np.ones(len(embeddings), dtype=bool)
+            for col, want in used.items():
+                vals = embeddings[col]
+                keep &= np.asarray(vals.isin(list(want)) if isinstance(want, (list, tuple, set)) else vals == want)
+            if keep.any():
+                rows = embeddings[keep]
+            else:
+                logger.warning('No embedding respect filters %s', filters)
+        pool = np.stack([np.asarray(e, dtype=np.float32) for e in rows['embedding'].values])
+    else:
+        pool = _to_numpy(embeddings)
+        if pool.ndim == 1:
+            pool = pool[None]
+    if isinstance(mode, (int, np.integer)) and not isinstance(mode, bool):
+        return pool[mode]
+    if callable(mode):
+        return mode(pool)
+    if mode in ('mean', 'avg', 'average'):
+        return pool.mean(axis=0)
+    if mode == 'random':
+        return pool[random.randrange(len(pool))]
+    raise ValueError("Unknown embedding selection mode !\n  Accepted : {}\n  Got : {}".format(
+        "(int, callable, 'mean', 'random')", mode))
+
+
+class SV2TTSTacotron2(Tacotron2):
+    """Tacotron2 conditioned on a speaker embedding (encoder output 512 + `embedding_dim`).  `infer(text, embeddings=...)`
+    takes the vector itself, or a selector resolved against the model's collection (`self.embeddings`): None -> the default
+    mode ('mean' when `use_label_embedding`, else 'random'), an int -> that row, a str -> that mode, a dict ->
+    `select_embedding(**dict)`; the reference's default is `embeddings=0`, the first row."""
+
+    def __init__(self, compiled_infer, lang='fr', *, embeddings=None, embedding_dim=256, use_label_embedding=False,
+                 encoder_name=None, **kwargs):
+        super().__init__(compiled_infer, lang=lang, **kwargs)
+        self.embeddings = embeddings
+        self.embedding_dim = embedding_dim
+        self.use_label_embedding = use_label_embedding
+        self.encoder_name = encoder_name
+
+    def select_embedding(self, embeddings=None, mode=None):
+        if not hasattr(embeddings, 'shape'):                     # a selector, not data
+            if mode is None:
+                mode = embeddings
+            embeddings = self.embeddings
+        if embeddings is None:
+            raise ValueError('this model has no speaker embeddings: pass `embeddings=<vector>` or set `model.embeddings`')
+        if mode is None:
+            mode = {'mode': 'mean' if self.use_label_embedding else 'random'}
+        elif not isinstance(mode, dict):
+            mode = {'mode': mode}
+        vec = np.asarray(select_embedding(embeddings, **mode), dtype=np.float32)
+        if vec.shape != (self.embedding_dim,):
+            raise ValueError(f'speaker embedding must have shape ({self.embedding_dim},), got {vec.shape}')
+        return vec
+
+    def infer(self, text, *, embeddings=0, **kwargs):
+        if embeddings is None or isinstance(embeddings, (int, str, dict)):
+            embeddings = self.select_embedding(embeddings)
+        return super().infer(text, embeddings=embeddings, **kwargs)
+
+    def _infer_overlapped(self, inputs, *, embeddings=0, **kwargs):
+        if embeddings is None or isinstance(embeddings, (int, str, dict)):
+            embeddings = self.select_embedding(embeddings)
+        return super()._infer_overlapped(inputs, embeddings=embeddings, **kwargs)
+
+
 def _as_callbacks(callbacks):
     """Accepts Callback instances, plain callables (called with the merged entry + result as keyword arguments, like the
     reference's `post_processing` functions) and queues."""
@@ -316,7 +393,9 @@ def get_models(path='synthetic', device=0, lang='en', overlap=False, **kwargs):
     `stream(..., overlap=True)` can run the two models concurrently."""
     from .runtime import HipRuntime, build_runtime
     from .waveglow import WaveGlow
-    key = (path, device, lang, bool(overlap))
+    spk_dim = int(kwargs.get('speaker_embedding_dim', 0) or 0)
+    embeddings = kwargs.pop('embeddings', None)
+    key = (path, device, lang, bool(overlap), spk_dim)
     if key not in _models:
         synth = build_runtime('hip', path, model='tacotron2', device=device, **kwargs)
         if overlap:
@@ -324,7 +403,11 @@ def get_models(path='synthetic', device=0, lang='en', overlap=False, **kwargs):
             voc = build_runtime('hip', path, model='waveglow', engine=eng, device=device, **kwargs)
         else:
             voc = build_runtime('hip', path, model='waveglow', engine=synth.engine, device=device, **kwargs)
-        _models[key] = (Tacotron2(synth, lang=lang), WaveGlow(voc))
+        model = (SV2TTSTacotron2(synth, lang=lang, embedding_dim=spk_dim, embeddings=embeddings) if spk_dim
+                 else Tacotron2(synth, lang=lang))
+        _models[key] = (model, WaveGlow(voc))
+    elif embeddings is not None and spk_dim:
+        _models[key][0].embeddings = embeddings
     return _models[key]
 
 

@@ -1,7 +1,8 @@
 """Host-side WaveGlow wrapper: the argument / return contract of the reference's `models.tts.WaveGlow.infer`.
 
-Restates /root/reference/models/tts/waveglow.py:61-142 (`infer`: path / 2-D / 3-D mel input, `audio_len = T * 256`,
-optional pad-to-`win_len` with -11, window / hop chunking with centre-half stitching) and :156-164 (`_get_steps`).
+Same behaviour as /root/reference/models/tts/waveglow.py:61-142 (`infer`: path / 2-D / 3-D mel input, `audio_len = T * 256`,
+optional pad-to-`win_len` with -11, window / hop chunking with centre-half stitching) and :156-164 (`_get_steps`),
+pinned by the known-answer tests in tests/test_host_logic.py.
 The compute call (`self.compiled_infer`) is a `HipRuntime`; nothing here touches a CPU fallback.
 """
 from __future__ import annotations
@@ -13,14 +14,18 @@ import numpy as np
 from .engine import _is_torch_cuda
 
 
-def _get_steps(length, win_len, hop_len):
-    """Window starts, evenly re-spaced so the last window ends at `length` (waveglow.py:156-164)."""
-    num_steps = int(math.ceil((length - win_len) / hop_len)) + 1
-    if num_steps == 1:
+def window_starts(length, win_len, hop_len):
+    """First frames of the analysis windows: the fewest windows of `win_len` frames, at most `hop_len` apart, that cover
+    `length` frames, re-spaced evenly so that the last one ends exactly at `length` (the rule of
+    models/tts/waveglow.py:156-164).  E.g. (1000, 256, 192) -> 0, 186, 372, 558, 744."""
+    n = 1 + max(0, int(math.ceil((length - win_len) / hop_len)))
+    if n == 1:
         return [0]
-    max_step = length - win_len
-    actual_step_size = max_step / (num_steps - 1)
-    return np.round(np.arange(num_steps) * actual_step_size).astype(np.int32)
+    spacing = (length - win_len) / (n - 1)
+    return np.round(spacing * np.arange(n)).astype(np.int32)
+
+
+_get_steps = window_starts          # the reference's name for it
 
 
 def _to_numpy(x):
@@ -72,7 +77,19 @@ def infer_tiled(compiled_infer, mel, z=None, tile_frames=4096, halo=HALO_FRAMES,
 
 
 class WaveGlow:
-    """`vocoder(mel, **kwargs)` object accepted by `Tacotron2.infer(..., vocoder=...)`."""
+    """`vocoder(mel, **kwargs)` object accepted by `Tacotron2.infer(..., vocoder=...)`: the argument / return contract of
+    the reference's `models.tts.WaveGlow.infer` (models/tts/waveglow.py:61-142).
+
+    mel: a `.npy` path, [T, 80] or [B, T, 80] -> audio [B, T * 256] (windowed single-utterance mode: [T * 256]).
+    Without `win_len` the whole mel is vocoded in one call.  With it (frames; a float means "a multiple of": rounded up,
+    or down with `use_slice`; capped by `max_win_len`):
+      * a mel that fits one window is vocoded directly -- padded to the window with -11 first only if `force_pad`
+        (default: only for the keras runtime, i.e. never here), the result cut back to T * 256 samples;
+      * a batch is vocoded directly;
+      * a longer utterance is cut into overlapping windows (`hop_len` frames apart; negative = window minus that many,
+        float = fraction of the window), each vocoded alone or all as one batch (`batch=True`), and stitched by dropping
+        half of every overlap from each side.  This is the reference's approximation (the vocoder's receptive field is
+        longer than the half-overlap); `infer_exact` is the exact alternative."""
     rate = 22050
     pad_mel_value = -11.
     runtime = 'hip'
@@ -80,68 +97,61 @@ class WaveGlow:
     def __init__(self, compiled_infer):
         self.compiled_infer = compiled_infer
 
+    def _resolve_window(self, n_frames, win_len, use_slice, max_win_len):
+        if isinstance(win_len, float):
+            count = max(1, n_frames // win_len) if use_slice else math.ceil(n_frames / win_len)
+            win_len = int(count * win_len) if not use_slice else int(count) * int(win_len)
+        return int(win_len if max_win_len is None else min(max_win_len, win_len))
+
+    def _pad_frames(self, mel, n_frames):
+        extra = n_frames - mel.shape[1]
+        if _is_torch_cuda(mel):
+            import torch
+            return torch.nn.functional.pad(mel, (0, 0, 0, extra), value=self.pad_mel_value)
+        return np.pad(np.asarray(mel), [(0, 0), (0, extra), (0, 0)], constant_values=self.pad_mel_value)
+
     def infer(self, mel, *, win_len=None, hop_len=-64, force_pad=None, batch=False, use_slice=False,
               max_win_len=None, **kwargs):
         if isinstance(mel, str):
             mel = np.load(mel)
         if len(mel.shape) == 2:
             mel = mel[None]
-        seq_len = mel.shape[1]
-        audio_len = seq_len * 256
+        n_frames = mel.shape[1]
+        n_samples = n_frames * 256
         if win_len is None:
-            return self.compiled_infer(mel, **kwargs)[:, :audio_len]
+            return self.compiled_infer(mel, **kwargs)[:, :n_samples]
 
-        if isinstance(win_len, float):
-            if not use_slice:
-                win_len = int(math.ceil(seq_len / win_len) * win_len)
-            else:
-                win_len = max(1, seq_len // win_len) * int(win_len)
-        if max_win_len is not None:
-            win_len = min(max_win_len, win_len)
+        win_len = self._resolve_window(n_frames, win_len, use_slice, max_win_len)
         kwargs['padding_multiple'] = win_len
-
-        if seq_len <= win_len:
+        if n_frames <= win_len:
             if force_pad is None:
-                force_pad = self.runtime == 'keras'         # False for this runtime (waveglow.py:95)
+                force_pad = self.runtime == 'keras'               # waveglow.py:95 -- False for this runtime
             if not force_pad:
                 return self.compiled_infer(mel)
-            win_len = max(win_len, seq_len)
-            pad = [(0, 0), (0, win_len - seq_len), (0, 0)]
-            if _is_torch_cuda(mel):
-                import torch
-                padded = torch.nn.functional.pad(mel, (0, 0, 0, win_len - seq_len), value=self.pad_mel_value)
-            else:
-                padded = np.pad(np.asarray(mel), pad, constant_values=self.pad_mel_value)
-            return self.compiled_infer(padded, **kwargs)[:, :audio_len]
-        elif mel.shape[0] > 1:
+            return self.compiled_infer(self._pad_frames(mel, win_len), **kwargs)[:, :n_samples]
+        if mel.shape[0] > 1:
             return self.compiled_infer(mel, **kwargs)
 
         if isinstance(hop_len, float):
             hop_len = int(win_len * hop_len)
         if hop_len < 0:
-            hop_len = win_len + hop_len
-
-        starts = _get_steps(seq_len, win_len, hop_len)
-        parts = [mel[:, start:start + win_len] for start in starts]
-        starts = np.asarray(starts)
-        overlaps = ((starts[:-1] + win_len) - starts[1:]) * 256
-
+            hop_len += win_len
+        starts = np.asarray(window_starts(n_frames, win_len, hop_len))
+        windows = [mel[:, s0:s0 + win_len] for s0 in starts]
         if batch:
             if _is_torch_cuda(mel):
                 import torch
-                stacked = torch.cat(parts, dim=0)
+                stacked = torch.cat(windows, dim=0)
             else:
-                stacked = np.concatenate([np.asarray(p) for p in parts], axis=0)
-            audio_parts = list(_to_numpy(self.compiled_infer(stacked, **kwargs)))
+                stacked = np.concatenate([np.asarray(w) for w in windows], axis=0)
+            pieces = list(_to_numpy(self.compiled_infer(stacked, **kwargs)))
         else:
-            audio_parts = [_to_numpy(self.compiled_infer(p, **kwargs)[0]) for p in parts]
-
-        audio = []
-        for i, part in enumerate(audio_parts):
-            start = 0 if i == 0 else overlaps[i - 1] // 2
-            end = None if i == len(audio_parts) - 1 else -overlaps[i] // 2
-            audio.append(part[start:end])
-        return np.concatenate(audio, axis=-1)
+            pieces = [_to_numpy(self.compiled_infer(w, **kwargs)[0]) for w in windows]
+        # consecutive windows share (end of k) - (start of k + 1) frames: each gives up half of those samples
+        shared = (starts[:-1] + win_len - starts[1:]) * 256
+        head = np.concatenate([[0], shared // 2])
+        tail = np.concatenate([-(-shared // 2), [0]])            # the reference slices `[: -overlap // 2]` = ceil half
+        return np.concatenate([p[h:len(p) - t] for p, h, t in zip(pieces, head, tail)], axis=-1)
 
     __call__ = infer
 
