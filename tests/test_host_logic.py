@@ -344,7 +344,8 @@ def test_select_embedding_modes():
     assert np.array_equal(select_embedding(pool, 1), pool[1])
     for m in ('mean', 'avg', 'average'):
         np.testing.assert_allclose(select_embedding(pool, m), pool.mean(0))
-    assert any(np.array_equal(select_embedding(pool, 'random'), r) for r in pool)
+    drawn = select_embedding(pool, 'random')
+    assert any(np.array_equal(drawn, r) for r in pool)
     assert np.array_equal(select_embedding(pool, lambda e: e[-1] * 2), pool[-1] * 2)
     assert np.array_equal(select_embedding(pool[0], 0), pool[0])             # a 1-D array is a collection of one
     with pytest.raises(ValueError, match='Unknown embedding selection mode'):
