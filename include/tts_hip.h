@@ -107,6 +107,15 @@ int tts_hip_tacotron2_infer_f16(tts_hip_engine* e, const int32_t* tokens, int B,
                                 float* mel, float* decoder_output, float* stop_tokens, float* attention,
                                 int32_t* lengths, int32_t* steps_run, int mem);
 
+/* How the autoregressive loop (tacotron2_arch.py:710-735, K.while_loop) is executed.  mode 1 (default): one persistent,
+ * weight-stationary cooperative kernel for the whole loop when the call shape allows it (batch <= 4, B * Tin small enough
+ * for LDS, a device with >= 256 CUs that can host the whole grid), otherwise -- and always with mode 0 -- one hipGraph of 7
+ * kernels per decoder step.  Both give the same results up to fp32 re-association.                                     */
+int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode);
+/* Which of the two the last tts_hip_tacotron2_infer* call on this handle used: 1 persistent kernel, 0 per-step graph (also
+ * after a fallback), -1 before the first call.                                                                          */
+int tts_hip_last_decoder_mode(const tts_hip_engine* e);
+
 /* ---- TacotronSTFT.mel_spectrogram  (utils/audio/stft.py:242-274,306-314)
  * audio [B, N] (N >= 1024) -> mel [B, N/256 + 1, 80]                                                                */
 int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem);

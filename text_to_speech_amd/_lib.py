@@ -15,7 +15,7 @@ LIB_NAME = 'libtts_hip.so'
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):
@@ -40,6 +40,8 @@ SIGNATURES = {
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     'tts_hip_tacotron2_infer_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                             c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    'tts_hip_set_decoder_mode': (c_int, [c_void_p, c_int]),
+    'tts_hip_last_decoder_mode': (c_int, [c_void_p]),
     'tts_hip_mel_stft': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
     'tts_hip_kernel_timing': (c_int, [c_void_p, c_int]),
     'tts_hip_kernel_time_us': (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),

@@ -104,6 +104,10 @@ struct Tacotron2Dev {
     float* loc_dense = nullptr;         // [128][32]   (transposed)
     float* proj_w = nullptr;            // [81][1024 + enc]  (80 mel rows + gate row)
     float* proj_b = nullptr;            // [81]
+    float* pfold_w = nullptr;           // [256][1024 + enc]  prenet layer 1 folded with the frame projection (taco_persist.hip)
+    float* pfold_b = nullptr;           // [256]
+    int persist_mode = 1;               // 1: use the persistent decoder when the call shape allows it; 0: per-step graph only
+    int last_path = -1;                 // how the last call ran its loop: 1 persistent kernel, 0 per-step graph
     ConvBnDev post_conv[5];
     std::vector<void*> allocs;
     DevBuf ws;                          // per-call workspace arena
@@ -125,6 +129,7 @@ struct TimedLaunch {
 
 struct tts_hip_engine {
     int device = 0;
+    int n_cu = 0;                       // compute units of `device`
     hipStream_t stream = nullptr;
     mutable std::string err;
     std::map<std::string, HostTensor> host;

@@ -72,7 +72,7 @@ void timing_collect(tts_hip_engine* e) {
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 5; }
+int tts_hip_abi_version(void) { return 6; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -84,6 +84,7 @@ int tts_hip_create(int device, tts_hip_engine** out) {
     tts_hip_engine* e = new (std::nothrow) tts_hip_engine();
     if (!e) return TTS_HIP_ENOMEM;
     e->device = device;
+    (void)hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, device);
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
         return TTS_HIP_EHIP;
@@ -360,6 +361,14 @@ int tts_hip_kernel_time_us(tts_hip_engine* e, int kind, double* avg_us, int64_t*
     if (launches) *launches = e->time_cnt[kind];
     return TTS_HIP_OK;
 }
+
+int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode) {
+    if (!e || (mode != 0 && mode != 1)) return set_err(e, TTS_HIP_EINVAL, "set_decoder_mode: mode must be 0 or 1");
+    e->taco.persist_mode = mode;
+    return TTS_HIP_OK;
+}
+
+int tts_hip_last_decoder_mode(const tts_hip_engine* e) { return e ? e->taco.last_path : -1; }
 
 int tts_hip_synchronize(tts_hip_engine* e) {
     if (!e) return TTS_HIP_EINVAL;

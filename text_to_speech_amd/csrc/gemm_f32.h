@@ -20,6 +20,8 @@
 #include <atomic>
 #include <stdint.h>
 
+#include "dev_util.h"
+
 // Timing ablations of the fp16 loop (TTS_ABL = 1..6; results are garbage when set) only exist in a build made with
 // -DTTS_DEBUG_HOOKS -DTTS_ABL=n; csrc/build.sh never passes either.
 #ifndef TTS_DEBUG_HOOKS
@@ -31,26 +33,7 @@
 
 namespace ttsgemm {
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only, and one process may own engines on
-// several GPUs: one flag per (kernel instantiation, device).  Two host threads may race here (stream(overlap=True) drives
-// two handles): the flags are atomic and setting the attribute twice is harmless.
-struct PerDeviceOnce {
-    static constexpr int kMaxDevices = 64;
-    std::atomic<bool> set[kMaxDevices];
-};
-inline hipError_t set_max_dyn_lds_once(const void* kern, size_t lds, PerDeviceOnce& once) {
-    int dev = -1;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const bool tracked = dev >= 0 && dev < PerDeviceOnce::kMaxDevices;
-    if (tracked && once.set[dev].load(std::memory_order_acquire)) return hipSuccess;
-    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess && tracked) once.set[dev].store(true, std::memory_order_release);
-    return e;
-}
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int MAX_SEG = 8;
@@ -116,7 +99,6 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // tanh(a) * sigmoid(b) = (E - 1) / ((E + 1) (1 + F)) with E = e^{2a}, F = e^{-b}: two v_exp_f32 and one v_rcp_f32 (1 ulp
 // each) instead of the libm tanhf / expf / IEEE division sequences, which made the gate epilogue ALU-bound (~0.3 ms of a
@@ -132,7 +114,6 @@ __device__ __forceinline__ float gate_tanh_sigmoid(float a, float b) {
 // Raw buffer loads: out-of-range offsets (>= num_records = 2^31) return 0, which gives branch-free zero fill for
 // rows outside the sequence / matrix (cdna_hip_programming.md T8).  Descriptors are built from wave-uniform values.
 constexpr unsigned OOB = 0x80000000u;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);

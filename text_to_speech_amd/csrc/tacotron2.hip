@@ -16,6 +16,7 @@
 // every kernel returns immediately once all rows are finished (device flag), which keeps the reference's
 // "stop as soon as every row has fired" semantics (:625-627) without a host round trip per step.
 #include "engine.h"
+#include "taco_persist.h"
 
 #include <atomic>
 #include <type_traits>
@@ -967,6 +968,8 @@ void tacotron2_free(tts_hip_engine* e) {
     e->taco.allocs.clear();
     e->taco.att.W16 = nullptr;
     e->taco.dec.W16 = nullptr;
+    e->taco.pfold_w = nullptr;
+    e->taco.pfold_b = nullptr;
     e->taco.ws.release();
     e->taco.io.release();
     e->taco.ready = false;
@@ -1104,6 +1107,7 @@ int tacotron2_finalize(tts_hip_engine* e) {
         TCHK(upload(e, pw.data(), pw.size(), &tc.proj_w, al));
         TCHK(upload(e, pb.data(), pb.size(), &tc.proj_b, al));
     }
+    TCHK(persist_finalize(e, p0, lk, lb, enc, al));       // prenet layer 1 folded with the projection (taco_persist.hip)
     {
         int cin = NMEL;
         for (int i = 0; i < 5; ++i) {
@@ -1186,7 +1190,11 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
     sz(R, 4); sz(R, 1); sz(B, 4); sz(R * 512, 4); sz(R * 512, 4); sz(R * 2048, 4); sz(R * enc, 4); sz(R * ATT, 4);
     sz((size_t)B * tc.spk_dim + 1, 4); sz((size_t)RD * 2 * PRE * (prenet_masks ? 1 : 0) + 1, 4);
+    const bool try_persist = persist_applicable(e, B, Tin);
+    const size_t n_xch = try_persist ? persist_xch_u64(B, Tin) : 0;
+    sz(try_persist ? (size_t)R * PERSIST_NPM : 1, 4);               // context folded through its consumers (persistent decoder)
     sz(64, 4);                                                      // DecState
+    sz(n_xch + 2, 8); sz(16, 4);                                    // persistent decoder: exchange area, flags
     sz((size_t)2 * B * 2 * 256, 8); sz(16, 4);                      // BiLSTM h exchange (tag, value) + error word
     sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4); sz(B * ATT, 4);
     sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
@@ -1209,7 +1217,10 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     float* d_pm = A.take<float>(R * ATT);
     float* d_spk = A.take<float>((size_t)B * tc.spk_dim + 1);
     float* d_masks = A.take<float>((size_t)RD * 2 * PRE * (prenet_masks ? 1 : 0) + 1);
+    float* d_pmfold = A.take<float>(try_persist ? (size_t)R * PERSIST_NPM : 1);
     DecState* d_state = A.take<DecState>(1);
+    unsigned long long* d_xch = A.take<unsigned long long>(n_xch + 2);
+    int* d_pflags = A.take<int>(16);
     unsigned long long* d_blh = A.take<unsigned long long>((size_t)2 * B * 2 * 256);
     int* d_blerr = A.take<int>(16);
     float* d_hatt = A.take<float>(2 * B * ARNN);
@@ -1389,7 +1400,46 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
         return TTS_HIP_OK;
     };
     int host_steps = 0;
-    {
+    bool persisted = false;
+    if (try_persist) {
+        // Persistent weight-stationary loop (taco_persist.hip): the attention context is folded through the four linear maps
+        // that consume it -- PM = memory x [W_att[:, ctx] | W_dec[:, ctx] | F[:, ctx] | P[:, ctx]] -- once per utterance.
+        struct Part { const float* Bt; long long ldb; int N, col; };
+        const Part parts[4] = {{tc.att.W + PRE, (long long)PRE + enc + ARNN, 4 * ARNN, PERSIST_COL_ATT},
+                               {tc.dec.W + ARNN, (long long)ARNN + enc + DRNN, 4 * DRNN, PERSIST_COL_DEC},
+                               {tc.pfold_w + DRNN, (long long)DRNN + enc, PRE, PERSIST_COL_F},
+                               {tc.proj_w + DRNN, (long long)DRNN + enc, NMEL + 1, PERSIST_COL_P}};
+        for (const Part& p : parts) {
+            GemmArgs g{};
+            g.M = (int)R;
+            g.N = p.N;
+            g.L = (int)R;
+            g.nseg = 1;
+            g.seg[0] = ASeg{d_memory, enc, 0, enc, enc};
+            g.Bt = p.Bt;
+            g.ldb = p.ldb;
+            g.mode = EPI_LINEAR;
+            g.split = p.N;
+            g.out0 = d_pmfold + p.col;
+            g.ld0 = PERSIST_NPM;
+            HIPCHK(e, gemm_small(g, 1, st));
+        }
+        int bl_err = 0;
+        HIPCHK(e, hipMemcpyAsync(&bl_err, d_blerr, sizeof bl_err, hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipStreamSynchronize(st));
+        if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
+        PersistCall pc{};
+        pc.B = B; pc.Tin = Tin; pc.max_len = max_len; pc.early_stop = early_stop ? 1 : 0;
+        pc.win_len = win_len; pc.win_off = win_offset; pc.half_w = half_w;
+        pc.memory = d_memory; pc.pm = d_pm; pc.mask = d_mask; pc.enc_len = d_enc_len; pc.masks = masks_dev;
+        pc.pm_fold = d_pmfold; pc.xch = d_xch; pc.flags = d_pflags;
+        pc.dec_out = d_decout; pc.stop_out = d_stop; pc.attn_hist = d_attn; pc.lengths = d_lengths; pc.finished = d_finished;
+        const int prc = persist_decode(e, st, pc, &host_steps);
+        if (prc < 0) return prc;
+        persisted = prc == TTS_HIP_OK;                  // 1: the grid could not become resident -> per-step graph below
+    }
+    tc.last_path = persisted ? 1 : 0;
+    if (!persisted) {
         // chunks of CHUNK steps; after each chunk the host reads the loop state (one 24-byte copy)
         DecState h{};
 #ifdef TTS_DEBUG_HOOKS

@@ -177,6 +177,19 @@ class HipEngine:
         self.last_steps = int(steps.value)
         return out
 
+    def set_decoder_mode(self, mode: str) -> None:
+        """'persistent' (default: one weight-stationary cooperative kernel for the whole decoder loop when the call shape
+        allows it) or 'graph' (always one hipGraph of 7 kernels per step)."""
+        modes = {'graph': 0, 'persistent': 1}
+        if mode not in modes:
+            raise ValueError(f'mode must be one of {tuple(modes)}, got {mode!r}')
+        self._check(self._lib.tts_hip_set_decoder_mode(self._h, modes[mode]), 'set_decoder_mode')
+
+    @property
+    def last_decoder_mode(self) -> str:
+        """How the last `tacotron2_infer` call ran its loop: 'persistent', 'graph', or 'none' before the first call."""
+        return {1: 'persistent', 0: 'graph'}.get(self._lib.tts_hip_last_decoder_mode(self._h), 'none')
+
     # ------------------------------------------------------------------ mel-STFT
     def mel_stft(self, audio):
         """audio [N] or [B, N] -> mel [B, N // 256 + 1, 80] (the reference's TacotronSTFT()(audio))."""
