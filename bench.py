@@ -119,10 +119,12 @@ def cpu_baseline(wg_weights, cfg, frames: int):
 
     mel, z = wg_inputs(frames)
     with torch.no_grad():
-        dt_np = with_threads(threads, lambda: waveglow_ref.infer(mel, wg_weights, cfg, z=z))
+        np_frames = max(8, frames // 4)                 # the numpy leg is ~3x slower than the torch one: a quarter of the frames
+        mel_n, z_n = wg_inputs(np_frames)
+        dt_np = with_threads(threads, lambda: waveglow_ref.infer(mel_n, wg_weights, cfg, z=z_n)) * frames / np_frames
         dt_th = with_threads(threads, lambda: torch_ref.torch_waveglow(mel, wg_weights, cfg, z))
-        legs['waveglow_numpy_all_threads'] = {'samples_per_s': frames * 256 / dt_np, 'threads': threads, 'frames': frames,
-                                              'seconds': dt_np}
+        legs['waveglow_numpy_all_threads'] = {'samples_per_s': frames * 256 / dt_np, 'threads': threads, 'frames': np_frames,
+                                              'seconds': dt_np * np_frames / frames}
         legs['waveglow_torch_all_threads'] = {'samples_per_s': frames * 256 / dt_th, 'threads': threads, 'frames': frames,
                                               'seconds': dt_th}
         small = max(8, frames // 10)
@@ -136,13 +138,14 @@ def cpu_baseline(wg_weights, cfg, frames: int):
         tcfg = Tacotron2Config()
         tw = weights.synth_tacotron2(tcfg, seed=1234)
         steps = 200
+        taco_threads = min(threads, 16)                 # GEMV-sized work: more threads only add synchronisation
         for B in (1, 8):
             tok = np.zeros((B, 128), np.int32)
             tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
-            dt_n = with_threads(threads, lambda: tacotron2_ref.infer(tok, tw, tcfg, max_length=steps, early_stopping=False))
-            dt_t = with_threads(threads, lambda: torch_ref.torch_tacotron2(tok, tw, tcfg, None, steps, None))
+            dt_n = with_threads(taco_threads, lambda: tacotron2_ref.infer(tok, tw, tcfg, max_length=steps, early_stopping=False))
+            dt_t = with_threads(taco_threads, lambda: torch_ref.torch_tacotron2(tok, tw, tcfg, None, steps, None))
             legs[f'tacotron2_batch{B}'] = {'mel_frames_per_s_numpy': B * steps / dt_n, 'mel_frames_per_s_torch': B * steps / dt_t,
-                                           'threads': threads, 'decoder_steps': steps, 'seconds': dt_n + dt_t}
+                                           'threads': taco_threads, 'decoder_steps': steps, 'seconds': dt_n + dt_t}
     torch.set_num_threads(threads)
     best = max(legs['waveglow_numpy_all_threads']['samples_per_s'], legs['waveglow_torch_all_threads']['samples_per_s'])
     which = 'torch.nn.functional (oneDNN/MKL)' if use_torch else 'numpy oracle (OpenBLAS)'
@@ -204,26 +207,46 @@ def secondary_metrics(eng, dev, rank):
     del mel8, z8
     eng.load_state(weights.synth_tacotron2(Tacotron2Config(), seed=1234))
     eng.finalize()
-    for B in (1, 8):
+    # Two ways to run the loop: 'persistent' = one weight-stationary cooperative kernel for the whole
+    # utterance (batch <= 4: no weight streaming at all, the step is bound by six CU-to-CU exchange hops), 'graph' = 7 kernels
+    # per step in a hipGraph, every LSTM weight streamed from HBM every step (the only path above batch 4).  The default
+    # ('persistent', falling back by itself) is what the plain keys report; `_graph` keys time the other path.
+    for B in (1, 2, 4, 8):
         tok = np.zeros((B, 128), np.int32)
         tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
         tok_d = torch.from_numpy(tok).to(dev)
-        for prec, tag, nbytes in (('f32', '', DECODER_STEP_BYTES_F32), ('f16', '_f16w', DECODER_STEP_BYTES_F16W)):
-            eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False, precision=prec)
-            # the call's fixed part (encoder, postnet, transfers) is separated from the per-step cost with two lengths
-            reps = 3
-            times = {}
-            for n_steps in (FRAMES // 2, FRAMES):
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    eng.tacotron2_infer(tok_d, max_len=n_steps, early_stopping=False, want_attention=False, precision=prec)
-                times[n_steps] = (time.perf_counter() - t0) / reps
-            dt = times[FRAMES]
-            step_us = 1e6 * (times[FRAMES] - times[FRAMES // 2]) / (FRAMES - FRAMES // 2)
-            out[f'tacotron2_batch{B}{tag}_mel_frames_per_s'] = B * FRAMES / dt
-            out[f'tacotron2_batch{B}{tag}_us_per_decoder_step'] = 1e6 * dt / FRAMES          # whole call / steps
-            out[f'tacotron2_batch{B}{tag}_us_per_decoder_step_marginal'] = step_us            # loop only
-            out[f'tacotron2_batch{B}{tag}_decoder_hbm_frac'] = nbytes / (step_us * 1e-6) / (HBM_PEAK_TBS * 1e12)
+        for mode in ('persistent', 'graph'):
+            eng.set_decoder_mode(mode)
+            for prec, tag, nbytes in (('f32', '', DECODER_STEP_BYTES_F32), ('f16', '_f16w', DECODER_STEP_BYTES_F16W)):
+                if B in (2, 4) and prec == 'f16':
+                    continue
+                eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False, precision=prec)
+                ran = eng.last_decoder_mode
+                if mode == 'graph' and B == 8:
+                    continue                              # batch 8 already ran on the graph path under 'persistent'
+                key = f'tacotron2_batch{B}{tag}' + ('' if mode == 'persistent' else '_graph')
+                # the call's fixed part (encoder, postnet, transfers) is separated from the per-step cost with two lengths
+                reps = 3
+                times = {}
+                for n_steps in (FRAMES // 2, FRAMES):
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        eng.tacotron2_infer(tok_d, max_len=n_steps, early_stopping=False, want_attention=False, precision=prec)
+                    times[n_steps] = (time.perf_counter() - t0) / reps
+                dt = times[FRAMES]
+                step_us = 1e6 * (times[FRAMES] - times[FRAMES // 2]) / (FRAMES - FRAMES // 2)
+                out[f'{key}_mel_frames_per_s'] = B * FRAMES / dt
+                out[f'{key}_us_per_decoder_step'] = 1e6 * dt / FRAMES          # whole call / steps
+                out[f'{key}_us_per_decoder_step_marginal'] = step_us            # loop only
+                out[f'{key}_decoder_path'] = ran
+                if ran == 'graph':
+                    # streaming roofline: all step weights once per step from HBM
+                    out[f'{key}_decoder_hbm_frac'] = nbytes / (step_us * 1e-6) / (HBM_PEAK_TBS * 1e12)
+                else:
+                    # weight-stationary: nothing is streamed; the bound is the exchange chain (6 hops x ~1.2 us measured
+                    # floor of one tagged CU-to-CU hop, scripts/micro/xcd_exchange.cpp)
+                    out[f'{key}_exchange_floor_frac'] = 6 * 1.2 / step_us
+    eng.set_decoder_mode('persistent')
     # BASELINE.json configs[2] shape: full text -> audio pipeline, batch 8, mixed token counts 50..200 padded to 256,
     # mel kept on the GPU between the two models, fp16 modes of both models (decoder LSTM weights fp16; WaveGlow GEMM
     # operands fp16; fp32 accumulation everywhere).

@@ -107,6 +107,31 @@ int tts_hip_tacotron2_infer_f16(tts_hip_engine* e, const int32_t* tokens, int B,
                                 float* mel, float* decoder_output, float* stop_tokens, float* attention,
                                 int32_t* lengths, int32_t* steps_run, int mem);
 
+/* ---- stream-ordered variants ("... , hipStream_t" entry points) ------------------------------------
+ * The calls above run on the handle's own stream and return when it has drained.  These take a caller `stream`
+ * (a hipStream_t passed as void*; NULL = the handle's stream), only accept device pointers, enqueue their work and return
+ * WITHOUT synchronizing, so a caller can queue transfers, several calls and its own kernels back to back.  A handle still
+ * has one workspace per model: two calls on the same handle must be ordered (same stream, or an event between streams).
+ * precision: 0 = f32, 1 = f16 operands, 2 = f16x3 (WaveGlow); 0 = f32, 1 = fp16 LSTM weights (Tacotron2).
+ *
+ * Tacotron2 in two calls -- Tacotron2Encoder (tacotron2_arch.py:235-333, once per batch) and the decoder loop + postnet
+ * (:609-749, :915-917):  `encode` is asynchronous and returns an opaque encoded batch (its own device buffer; free it with
+ * tts_hip_encoded_free; several may be alive, e.g. the next sentence's encoder running ahead); `decode` may be called any
+ * number of times on it (the retry loop of models/tts/tacotron2.py:160-179 re-runs only the decoder with new dropout
+ * masks) and synchronizes `stream` before it returns, because the loop's exit is data dependent and `steps_run` is a host
+ * value.  tts_hip_tacotron2_infer == encode + decode.                                                                  */
+typedef struct tts_hip_encoded tts_hip_encoded;
+int tts_hip_waveglow_infer_async(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                                 float* audio, int precision, void* stream);
+int tts_hip_mel_stft_async(tts_hip_engine* e, const float* audio, int B, int N, float* mel, void* stream);
+int tts_hip_tacotron2_encode(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker, int mem,
+                             void* stream, tts_hip_encoded** out);
+int tts_hip_tacotron2_decode(tts_hip_engine* e, const tts_hip_encoded* encoded, int max_len, int early_stop,
+                             const float* prenet_masks, int win_len, int win_offset, int precision, float* mel,
+                             float* decoder_output, float* stop_tokens, float* attention, int32_t* lengths,
+                             int32_t* steps_run, int mem, void* stream);
+int tts_hip_encoded_free(tts_hip_engine* e, tts_hip_encoded* encoded);
+
 /* How the autoregressive loop (tacotron2_arch.py:710-735, K.while_loop) is executed.  mode 1 (default): one persistent,
  * weight-stationary cooperative kernel for the whole loop when the call shape allows it (batch <= 4, B * Tin small enough
  * for LDS, a device with >= 256 CUs that can host the whole grid), otherwise -- and always with mode 0 -- one hipGraph of 7

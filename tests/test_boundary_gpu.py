@@ -1,0 +1,100 @@
+"""GPU: the stream-ordered half of the C ABI: tts_hip_tacotron2_encode / _decode, the *_async calls
+on a caller's stream, replay of cached decoder graphs, and the encoder reuse of the reference's retry loop."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tokens(B, Tin, lens, seed=0):
+    rng = np.random.default_rng(seed)
+    tok = rng.integers(1, 148, (B, Tin)).astype(np.int32)
+    for b, n in enumerate(lens):
+        tok[b, n:] = 0
+    return tok
+
+
+@pytest.mark.parametrize('mode', ['persistent', 'graph'])
+def test_encode_then_decode_equals_infer_and_can_be_repeated(gpu_engine, taco_weights, taco_cfg, mode):
+    from oracle import tacotron2_ref
+    gpu_engine.set_decoder_mode(mode)
+    try:
+        tok = _tokens(2, 33, [33, 21], seed=3)
+        rng = np.random.default_rng(1)
+        m1 = (rng.random((2, 24, 2, 256)) >= 0.5).astype(np.float32) * 2.0
+        m2 = (rng.random((2, 40, 2, 256)) >= 0.5).astype(np.float32) * 2.0
+        whole = gpu_engine.tacotron2_infer(tok, max_len=24, early_stopping=False, prenet_masks=m1)
+        enc = gpu_engine.tacotron2_encode(tok)
+        a = gpu_engine.tacotron2_decode(enc, max_len=24, early_stopping=False, prenet_masks=m1)
+        assert gpu_engine.last_decoder_mode == mode
+        for k in ('mel', 'decoder_output', 'stop_tokens', 'attention_weights', 'lengths'):
+            assert np.array_equal(getattr(a, k), getattr(whole, k)), k          # same kernels, same inputs
+        # a second decode of the same encoded batch: other masks, other length (the retry loop of tacotron2.py:160-179)
+        b = gpu_engine.tacotron2_decode(enc, max_len=40, early_stopping=False, prenet_masks=m2)
+        ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=40, early_stopping=False, prenet_masks=m2)
+        assert np.abs(b.mel - ref.mel).max() <= 1e-3 and np.array_equal(b.lengths, ref.lengths)
+        # and the first one again: a cached graph of the 256-step bucket is replayed with different masks / max_len
+        c = gpu_engine.tacotron2_decode(enc, max_len=24, early_stopping=False, prenet_masks=m1)
+        assert np.array_equal(c.mel, a.mel)
+        enc.close()
+        with pytest.raises(ValueError, match='freed'):
+            gpu_engine.tacotron2_decode(enc, max_len=4)
+    finally:
+        gpu_engine.set_decoder_mode('persistent')
+
+
+def test_cached_decoder_graphs_survive_shape_changes(gpu_engine, taco_weights, taco_cfg):
+    """Per-step graph path: calls alternate between shapes (each has its own cached executable graph), a larger call grows
+    the workspace (which drops every cached graph), and every result still matches the oracle."""
+    from oracle import tacotron2_ref
+    gpu_engine.set_decoder_mode('graph')
+    try:
+        cases = [(1, 20, 40), (3, 26, 37), (1, 20, 33), (3, 26, 37), (9, 12, 70), (1, 20, 40)]
+        for i, (B, Tin, T) in enumerate(cases):
+            tok = _tokens(B, Tin, [Tin - b for b in range(B)], seed=B)
+            ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=T, early_stopping=False)
+            out = gpu_engine.tacotron2_infer(tok, max_len=T, early_stopping=False)
+            assert gpu_engine.last_decoder_mode == 'graph' and gpu_engine.last_steps == T
+            assert np.abs(out.mel - ref.mel).max() <= 1e-3, (i, B, Tin, T)
+            assert np.abs(out.attention_weights - ref.attention_weights).max() <= 1e-3
+    finally:
+        gpu_engine.set_decoder_mode('persistent')
+
+
+def test_async_calls_on_a_torch_stream_match_the_blocking_calls(gpu_engine):
+    import torch
+    rng = np.random.default_rng(0)
+    mel = torch.from_numpy(rng.uniform(-11.5, 1.2, (2, 12, 80)).astype(np.float32)).cuda()
+    z = torch.from_numpy(rng.standard_normal((2, 12 * 32, 8)).astype(np.float32)).cuda()
+    wav = torch.from_numpy(rng.uniform(-1, 1, (2, 5000)).astype(np.float32)).cuda()
+    ref_audio = {p: gpu_engine.waveglow_infer(mel, z=z, precision=p) for p in ('f32', 'f16', 'f16x3')}
+    ref_mel = gpu_engine.mel_stft(wav)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        mel_s = mel * 1.0                                       # produced on `s`: the engine call must be ordered after it
+        outs = {p: gpu_engine.waveglow_infer(mel_s, z=z, precision=p, stream=s) for p in ('f32', 'f16', 'f16x3')}
+        m = gpu_engine.mel_stft(wav, stream=s)
+        doubled = outs['f32'] * 2.0                              # consumed on `s` without any host synchronization
+    s.synchronize()
+    for p in outs:
+        assert torch.equal(outs[p], ref_audio[p]), p
+    assert torch.equal(m, ref_mel) and torch.equal(doubled, ref_audio['f32'] * 2.0)
+    with pytest.raises(ValueError, match='device tensors'):
+        gpu_engine.waveglow_infer(mel.cpu().numpy(), stream=s)
+
+
+def test_runtime_retry_reuses_the_encoder(gpu_engine, taco_weights, taco_cfg):
+    """The reference's retry loop calls compiled_infer again with the same tokens (fresh dropout): the runtime keeps the
+    encoded batch and only re-runs the decoder; a different sentence encodes again."""
+    from oracle import tacotron2_ref
+    from text_to_speech_amd.runtime import HipRuntime
+    rt = HipRuntime('retry', model='tacotron2', engine=gpu_engine, seed=0)
+    tok = _tokens(1, 30, [30], seed=8)
+    a = rt(tok, max_length=12, early_stopping=False, seed=1)
+    b = rt(tok, max_length=12, early_stopping=False, seed=2)                     # retry: new masks, same tokens
+    assert rt.encoder_reuses == 1 and not np.array_equal(a.mel, b.mel)
+    c = rt(tok, max_length=12, early_stopping=False, deterministic=True)
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=12, early_stopping=False)
+    assert rt.encoder_reuses == 2 and np.abs(c.mel - ref.mel).max() <= 1e-3
+    rt(_tokens(1, 30, [30], seed=9), max_length=12, early_stopping=False, deterministic=True)
+    assert rt.encoder_reuses == 2

@@ -15,7 +15,7 @@ LIB_NAME = 'libtts_hip.so'
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HipLibraryError(RuntimeError):
@@ -43,6 +43,12 @@ SIGNATURES = {
     'tts_hip_set_decoder_mode': (c_int, [c_void_p, c_int]),
     'tts_hip_last_decoder_mode': (c_int, [c_void_p]),
     'tts_hip_mel_stft': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
+    'tts_hip_waveglow_infer_async': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
+    'tts_hip_mel_stft_async': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'tts_hip_tacotron2_encode': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, POINTER(c_void_p)]),
+    'tts_hip_tacotron2_decode': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'tts_hip_encoded_free': (c_int, [c_void_p, c_void_p]),
     'tts_hip_kernel_timing': (c_int, [c_void_p, c_int]),
     'tts_hip_kernel_time_us': (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     'tts_hip_synchronize': (c_int, [c_void_p]),

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/tts_hip.h"
@@ -87,6 +88,29 @@ struct LstmDev {                // weights packed gate-interleaved: row r = 4*u 
     _Float16* W16 = nullptr;    // fp16 copy of W for tts_hip_tacotron2_infer_f16 (built on first use)
     int units = 0, kin = 0;
 };
+// Output of the Tacotron2 encoder for one batch (tts_hip_tacotron2_encode): what the decoder loop needs, in its own device
+// buffer so that several encoded batches can be alive at once.
+struct tts_hip_encoded {
+    int B = 0, Tin = 0, enc = 0;
+    DevBuf buf;
+    uint8_t* mask = nullptr;            // [B * Tin]  token != pad
+    int* enc_len = nullptr;             // [B]
+    int* bl_err = nullptr;              // BiLSTM block-exchange status (0 = ok), checked at the decoder's first synchronization
+    float* memory = nullptr;            // [B * Tin][enc]
+    float* pm = nullptr;                // [B * Tin][128]  processed memory
+};
+
+// Identity of an instantiated decoder-chunk hipGraph: every pointer and scalar its 225 kernel nodes have baked in.
+struct DecGraphKey {
+    const void* ws;
+    const void* enc_buf;
+    int B, Tin, max_len_bucket, masks, win_len, win_off, half_w, persist_layout;
+    bool operator<(const DecGraphKey& o) const {
+        return std::tie(ws, enc_buf, B, Tin, max_len_bucket, masks, win_len, win_off, half_w, persist_layout) <
+               std::tie(o.ws, o.enc_buf, o.B, o.Tin, o.max_len_bucket, o.masks, o.win_len, o.win_off, o.half_w, o.persist_layout);
+    }
+};
+
 struct Tacotron2Dev {
     bool ready = false;
     int enc_dim = 512, spk_dim = 0;
@@ -112,6 +136,9 @@ struct Tacotron2Dev {
     std::vector<void*> allocs;
     DevBuf ws;                          // per-call workspace arena
     DevBuf io;                          // staging for host callers
+    tts_hip_encoded* enc_cache = nullptr;                 // encoder output of tts_hip_tacotron2_infer* calls (reused: stable pointers)
+    std::map<DecGraphKey, hipGraphExec_t> graphs;         // instantiated decoder-chunk graphs, replayed across calls
+    std::vector<DecGraphKey> graph_order;                 // insertion order (oldest evicted first)
 };
 
 struct MelStftDev {
@@ -145,6 +172,18 @@ struct tts_hip_engine {
 };
 
 int set_err(const tts_hip_engine* e, int code, const char* fmt, ...);
+
+// Calls on one handle are serialised by the caller; for the duration of a call its work goes to `stream` when the caller
+// passed one (the *_async entry points, tacotron2 encode / decode), else to the handle's own stream.
+struct StreamScope {
+    tts_hip_engine* e;
+    hipStream_t saved;
+    StreamScope(tts_hip_engine* eng, void* stream) : e(eng), saved(eng->stream) {
+        if (stream) e->stream = (hipStream_t)stream;
+    }
+    ~StreamScope() { e->stream = saved; }
+};
+void tacotron2_graphs_clear(tts_hip_engine* e);
 
 #define HIPCHK(e, call)                                                                                         \
     do {                                                                                                        \

@@ -72,7 +72,7 @@ void timing_collect(tts_hip_engine* e) {
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 6; }
+int tts_hip_abi_version(void) { return 7; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -317,6 +317,38 @@ int tts_hip_waveglow_infer_f16(tts_hip_engine* e, const float* mel, int B, int T
 int tts_hip_waveglow_infer_f16x3(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
                                  float* audio, int mem) {
     return waveglow_infer_impl(e, mel, B, T, z, sigma, audio, mem, 2);
+}
+
+// Device-pointer variants on a caller stream: enqueue and return (no synchronization).  Same arithmetic as the calls above.
+int tts_hip_waveglow_infer_async(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
+                                 float* audio, int precision, void* stream) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (precision < 0 || precision > 2) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer_async: precision must be 0 (f32), 1 (f16) or 2 (f16x3)");
+    if (!e->wg.ready) return set_err(e, TTS_HIP_ENOTREADY, "waveglow weights not finalized");
+    if (!mel || !audio || B <= 0 || T <= 0) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer_async: bad argument");
+    constexpr int kMaxFramesPerRun = 31744;
+    if (T > kMaxFramesPerRun)
+        return set_err(e, TTS_HIP_EINVAL, "waveglow_infer_async: T = %d frames exceeds one run's limit (%d); use windowed inference",
+                       T, kMaxFramesPerRun);
+    HIPCHK(e, hipSetDevice(e->device));
+    StreamScope scope(e, stream);
+    const int chunkB = kMaxFramesPerRun / T;
+    for (int b0 = 0; b0 < B; b0 += chunkB) {
+        const int nb = B - b0 < chunkB ? B - b0 : chunkB;
+        int rc = waveglow_run(e, mel + (size_t)b0 * T * 80, nb, T, z ? z + (size_t)b0 * T * 32 * 8 : nullptr, sigma,
+                              audio + (size_t)b0 * T * 256, precision);
+        if (rc) return rc;
+    }
+    return TTS_HIP_OK;
+}
+
+int tts_hip_mel_stft_async(tts_hip_engine* e, const float* audio, int B, int N, float* mel, void* stream) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (!e->stft.ready) return set_err(e, TTS_HIP_ENOTREADY, "mel_stft not finalized");
+    if (!audio || !mel || B <= 0 || N < 1024) return set_err(e, TTS_HIP_EINVAL, "mel_stft_async: bad argument (N >= 1024)");
+    HIPCHK(e, hipSetDevice(e->device));
+    StreamScope scope(e, stream);
+    return melstft_run(e, audio, B, N, mel);
 }
 
 int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem) {

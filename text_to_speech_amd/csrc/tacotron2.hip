@@ -970,6 +970,12 @@ void tacotron2_free(tts_hip_engine* e) {
     e->taco.dec.W16 = nullptr;
     e->taco.pfold_w = nullptr;
     e->taco.pfold_b = nullptr;
+    tacotron2_graphs_clear(e);
+    if (e->taco.enc_cache) {
+        e->taco.enc_cache->buf.release();
+        delete e->taco.enc_cache;
+        e->taco.enc_cache = nullptr;
+    }
     e->taco.ws.release();
     e->taco.io.release();
     e->taco.ready = false;
@@ -1124,28 +1130,6 @@ int tacotron2_finalize(tts_hip_engine* e) {
     return TTS_HIP_OK;
 }
 
-static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
-                                int max_len, int early_stop, const float* prenet_masks, int win_len,
-                                int win_offset, float* mel, float* decoder_output, float* stop_tokens,
-                                float* attention, int32_t* lengths, int32_t* steps_run, int mem, bool half_w);
-
-extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
-                                       int max_len, int early_stop, const float* prenet_masks, int win_len,
-                                       int win_offset, float* mel, float* decoder_output, float* stop_tokens,
-                                       float* attention, int32_t* lengths, int32_t* steps_run, int mem) {
-    return tacotron2_infer_impl(e, tokens, B, Tin, speaker, max_len, early_stop, prenet_masks, win_len, win_offset, mel,
-                                decoder_output, stop_tokens, attention, lengths, steps_run, mem, false);
-}
-
-extern "C" int tts_hip_tacotron2_infer_f16(tts_hip_engine* e, const int32_t* tokens, int B, int Tin,
-                                           const float* speaker, int max_len, int early_stop,
-                                           const float* prenet_masks, int win_len, int win_offset, float* mel,
-                                           float* decoder_output, float* stop_tokens, float* attention,
-                                           int32_t* lengths, int32_t* steps_run, int mem) {
-    return tacotron2_infer_impl(e, tokens, B, Tin, speaker, max_len, early_stop, prenet_masks, win_len, win_offset, mel,
-                                decoder_output, stop_tokens, attention, lengths, steps_run, mem, true);
-}
-
 // fp16 copies of the two decoder LSTM weight matrices (98 % of the bytes a decoder step streams), built on first use
 static int tacotron2_build_f16(tts_hip_engine* e) {
     Tacotron2Dev& tc = e->taco;
@@ -1164,110 +1148,84 @@ static int tacotron2_build_f16(tts_hip_engine* e) {
     return TTS_HIP_OK;
 }
 
-static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
-                                int max_len, int early_stop, const float* prenet_masks, int win_len,
-                                int win_offset, float* mel, float* decoder_output, float* stop_tokens,
-                                float* attention, int32_t* lengths, int32_t* steps_run, int mem, bool half_w) {
-    if (!e) return TTS_HIP_EINVAL;
+void tacotron2_graphs_clear(tts_hip_engine* e) {
+    for (auto& kv : e->taco.graphs) (void)hipGraphExecDestroy(kv.second);
+    e->taco.graphs.clear();
+    e->taco.graph_order.clear();
+}
+
+// ---------------------------------------------------------------------------------------------------------- encoder
+// tokens -> (mask, lengths, memory, processed memory) in `out` (its own device buffer, so several encoded utterances can
+// be alive); temporaries live in the engine workspace.  Everything is enqueued on e->stream; nothing is synchronized.
+static int tacotron2_encode_impl(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker, int mem,
+                                 tts_hip_encoded* out) {
     Tacotron2Dev& tc = e->taco;
     if (!tc.ready) return set_err(e, TTS_HIP_ENOTREADY, "tacotron2 weights not finalized");
-    if (half_w) {
-        int rc16 = tacotron2_build_f16(e);
-        if (rc16) return rc16;
-    }
-    if (!tokens || B <= 0 || Tin <= 0 || max_len <= 0 || Tin > 4096 || B > 1024)
-        return set_err(e, TTS_HIP_EINVAL, "tacotron2_infer: bad argument");
-    if (tc.spk_dim > 0 && !speaker) return set_err(e, TTS_HIP_EINVAL, "tacotron2_infer: this model needs a speaker embedding");
+    if (!tokens || !out || B <= 0 || Tin <= 0 || Tin > 4096 || B > 1024)
+        return set_err(e, TTS_HIP_EINVAL, "tacotron2_encode: bad argument");
+    if (tc.spk_dim > 0 && !speaker) return set_err(e, TTS_HIP_EINVAL, "tacotron2_encode: this model needs a speaker embedding");
     if (mem != TTS_HIP_MEM_HOST && mem != TTS_HIP_MEM_DEVICE) return set_err(e, TTS_HIP_EINVAL, "bad mem kind %d", mem);
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
     const int enc = tc.enc_dim;
-    const long long R = (long long)B * Tin;          // encoder rows
-    const long long RD = (long long)B * max_len;     // decoder rows
+    const long long R = (long long)B * Tin;
 
-    // ---------------- workspace arena
+    // result buffer
+    {
+        size_t need = 0;
+        auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
+        sz(R, 1); sz(B, 4); sz(16, 4); sz(R * enc, 4); sz(R * ATT, 4);
+        need += 1024;
+        const void* before = out->buf.p;
+        HIPCHK(e, out->buf.ensure(need));
+        if (out->buf.p != before) tacotron2_graphs_clear(e);      // captured graphs hold pointers into this buffer
+        Arena A;
+        A.base = (char*)out->buf.p;
+        A.cap = out->buf.bytes;
+        out->mask = A.take<uint8_t>(R);
+        out->enc_len = A.take<int>(B);
+        out->bl_err = A.take<int>(16);
+        out->memory = A.take<float>(R * enc);
+        out->pm = A.take<float>(R * ATT);
+        out->B = B;
+        out->Tin = Tin;
+        out->enc = enc;
+    }
+    // temporaries
     size_t need = 0;
     auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
-    sz(R, 4); sz(R, 1); sz(B, 4); sz(R * 512, 4); sz(R * 512, 4); sz(R * 2048, 4); sz(R * enc, 4); sz(R * ATT, 4);
-    sz((size_t)B * tc.spk_dim + 1, 4); sz((size_t)RD * 2 * PRE * (prenet_masks ? 1 : 0) + 1, 4);
-    const bool try_persist = persist_applicable(e, B, Tin);
-    const size_t n_xch = try_persist ? persist_xch_u64(B, Tin) : 0;
-    sz(try_persist ? (size_t)R * PERSIST_NPM : 1, 4);               // context folded through its consumers (persistent decoder)
-    sz(64, 4);                                                      // DecState
-    sz(n_xch + 2, 8); sz(16, 4);                                    // persistent decoder: exchange area, flags
-    sz((size_t)2 * B * 2 * 256, 8); sz(16, 4);                      // BiLSTM h exchange (tag, value) + error word
-    sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4); sz(B * ATT, 4);
-    sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
-    sz(RD * NMEL, 4); sz(RD, 4); sz(RD * Tin, 4); sz(RD, 1); sz(RD * NMEL, 4); sz(RD * 512, 4); sz(RD * 512, 4);
-    sz(RD * NMEL, 4); sz(RD * NMEL, 4);
-    const size_t conv_rows = (size_t)std::min<long long>(std::max(R, RD), 32768);     // 512 tiles x 64 rows at most
+    sz(R, 4); sz(R * 512, 4); sz(R * 512, 4); sz(R * 2048, 4); sz((size_t)B * tc.spk_dim + 1, 4); sz((size_t)2 * B * 2 * 256, 8);
+    const size_t conv_rows = (size_t)std::min<long long>(R, 32768);
     sz(5 * conv_rows * 512, 4);
     need += 4096;
-    HIPCHK(e, tc.ws.ensure(need));
+    {
+        const void* before = tc.ws.p;
+        HIPCHK(e, tc.ws.ensure(need));
+        if (tc.ws.p != before) tacotron2_graphs_clear(e);
+    }
     Arena A;
     A.base = (char*)tc.ws.p;
     A.cap = tc.ws.bytes;
     int* d_tok = A.take<int>(R);
-    uint8_t* d_mask = A.take<uint8_t>(R);
-    int* d_enc_len = A.take<int>(B);
     float* d_x0 = A.take<float>(R * 512);
     float* d_x1 = A.take<float>(R * 512);
     float* d_xproj = A.take<float>(R * 2048);
-    float* d_memory = A.take<float>(R * enc);
-    float* d_pm = A.take<float>(R * ATT);
     float* d_spk = A.take<float>((size_t)B * tc.spk_dim + 1);
-    float* d_masks = A.take<float>((size_t)RD * 2 * PRE * (prenet_masks ? 1 : 0) + 1);
-    float* d_pmfold = A.take<float>(try_persist ? (size_t)R * PERSIST_NPM : 1);
-    DecState* d_state = A.take<DecState>(1);
-    unsigned long long* d_xch = A.take<unsigned long long>(n_xch + 2);
-    int* d_pflags = A.take<int>(16);
     unsigned long long* d_blh = A.take<unsigned long long>((size_t)2 * B * 2 * 256);
-    int* d_blerr = A.take<int>(16);
-    float* d_hatt = A.take<float>(2 * B * ARNN);
-    float* d_catt = A.take<float>(B * ARNN);
-    float* d_hdec = A.take<float>(2 * B * DRNN);
-    float* d_cdec = A.take<float>(B * DRNN);
-    float* d_ctx = A.take<float>(B * enc);
-    float* d_p2 = A.take<float>(B * PRE);
-    float* d_q = A.take<float>(B * ATT);
-    float* d_frame = A.take<float>(B * NMEL);
-    float* d_energy = A.take<float>(R);
-    float* d_wprev = A.take<float>(R);
-    float* d_wcum = A.take<float>(R);
-    int* d_finished = A.take<int>(B);
-    int* d_lengths = A.take<int>(B);
-    int* d_mainatt = A.take<int>(2 * B);
-    float* d_decout = A.take<float>(RD * NMEL);
-    float* d_stop = A.take<float>(RD);
-    float* d_attn = A.take<float>(RD * Tin);
-    uint8_t* d_dmask = A.take<uint8_t>(RD);
-    float* d_xm = A.take<float>(RD * NMEL);
-    float* d_pa = A.take<float>(RD * 512);
-    float* d_pb = A.take<float>(RD * 512);
-    float* d_post = A.take<float>(RD * NMEL);
-    float* d_mel = A.take<float>(RD * NMEL);
     float* d_convtmp = A.take<float>(5 * conv_rows * 512);
     const size_t convtmp_n = 5 * conv_rows * 512;
     if (A.off > A.cap) return set_err(e, TTS_HIP_ENOMEM, "tacotron2 workspace accounting error");
-    const size_t zero_from = (char*)d_state - A.base, zero_to = (char*)d_dmask - A.base;
+    uint8_t* d_mask = out->mask;
+    int* d_enc_len = out->enc_len;
+    float* d_memory = out->memory;
+    float* d_pm = out->pm;
 
-    // ---------------- inputs
     const hipMemcpyKind kin = mem == TTS_HIP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     HIPCHK(e, hipMemcpyAsync(d_tok, tokens, R * 4, kin, st));
     if (tc.spk_dim) HIPCHK(e, hipMemcpyAsync(d_spk, speaker, (size_t)B * tc.spk_dim * 4, kin, st));
-    const float* masks_dev = nullptr;
-    if (prenet_masks) {
-        if (mem == TTS_HIP_MEM_HOST) {
-            HIPCHK(e, hipMemcpyAsync(d_masks, prenet_masks, (size_t)RD * 2 * PRE * 4, kin, st));
-            masks_dev = d_masks;
-        } else {
-            masks_dev = prenet_masks;
-        }
-    }
-    // all recurrent state, loop state, histories and outputs start at zero
-    HIPCHK(e, hipMemsetAsync(A.base + zero_from, 0, zero_to - zero_from, st));
+    HIPCHK(e, hipMemsetAsync(d_blh, 0, (size_t)2 * B * 2 * 256 * 8, st));
+    HIPCHK(e, hipMemsetAsync(out->bl_err, 0, 16 * 4, st));
 
-    // ---------------- encoder
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)R), dim3(128), 0, st, d_tok, tc.embeddings, d_x0, d_mask, (int)R, 148);
     HIPCHK(e, hipGetLastError());
     hipLaunchKernelGGL(enc_len_kernel, dim3(B), dim3(64), 0, st, d_mask, d_enc_len, Tin);
@@ -1296,7 +1254,7 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
         HIPCHK(e, gemm_small(g, 1, st));
     }
     hipLaunchKernelGGL(bilstm_kernel, dim3(BL_Q, 2, B), dim3(1024), 0, st, d_xproj, tc.bl_rec[0], tc.bl_rec[1], d_mask,
-                       d_memory, d_blh, d_blerr, Tin, enc);
+                       d_memory, d_blh, out->bl_err, Tin, enc);
     HIPCHK(e, hipGetLastError());
     if (tc.spk_dim) {
         const long long n = R * tc.spk_dim;
@@ -1318,6 +1276,107 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
         g.out0 = d_pm;
         g.ld0 = ATT;
         HIPCHK(e, gemm_small(g, 1, st));
+    }
+    return TTS_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------- decoder
+// Autoregressive loop + postnet from an encoded batch.  Enqueued on e->stream; synchronizes it before returning (the
+// loop's exit is data dependent and `steps_run` / the BiLSTM status are host values).
+static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, int max_len, int early_stop,
+                                 const float* prenet_masks, int win_len, int win_offset, float* mel,
+                                 float* decoder_output, float* stop_tokens, float* attention, int32_t* lengths,
+                                 int32_t* steps_run, int mem, bool half_w) {
+    Tacotron2Dev& tc = e->taco;
+    if (!tc.ready) return set_err(e, TTS_HIP_ENOTREADY, "tacotron2 weights not finalized");
+    if (!en || !en->buf.p || en->B <= 0 || max_len <= 0) return set_err(e, TTS_HIP_EINVAL, "tacotron2_decode: bad argument");
+    if (en->enc != tc.enc_dim) return set_err(e, TTS_HIP_EINVAL, "tacotron2_decode: encoded batch belongs to other weights");
+    if (mem != TTS_HIP_MEM_HOST && mem != TTS_HIP_MEM_DEVICE) return set_err(e, TTS_HIP_EINVAL, "bad mem kind %d", mem);
+    if (half_w) {
+        int rc16 = tacotron2_build_f16(e);
+        if (rc16) return rc16;
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const int B = en->B, Tin = en->Tin, enc = tc.enc_dim;
+    const long long R = (long long)B * Tin;          // encoder rows
+    const long long RD = (long long)B * max_len;     // decoder rows
+    // Buffers the step kernels address are sized for max_len rounded up to a bucket, so that every call of a bucket has
+    // the same workspace layout and can replay the same instantiated hipGraph (rows are indexed with the real max_len,
+    // which the kernels read from the device-side loop state).
+    const long long max_len_b = (max_len + 255) / 256 * 256;
+    const long long RB = (long long)B * max_len_b;
+    uint8_t* d_mask = en->mask;
+    int* d_enc_len = en->enc_len;
+    float* d_memory = en->memory;
+    float* d_pm = en->pm;
+
+    // ---------------- workspace arena
+    const bool try_persist = persist_applicable(e, B, Tin);
+    const size_t n_xch = try_persist ? persist_xch_u64(B, Tin) : 0;
+    const size_t n_masks = prenet_masks ? (size_t)RB * 2 * PRE : 1;
+    const size_t conv_rows = (size_t)std::min<long long>(RD, 32768);     // 512 tiles x 64 rows at most
+    size_t need = 0;
+    auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
+    sz(n_masks, 4); sz(try_persist ? (size_t)R * PERSIST_NPM : 1, 4);
+    sz(64, 4); sz(n_xch + 2, 8); sz(16, 4);
+    sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4); sz(B * ATT, 4);
+    sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
+    sz(RB * NMEL, 4); sz(RB, 4); sz(RB * Tin, 4); sz(RD, 1); sz(RD * NMEL, 4); sz(RD * 512, 4); sz(RD * 512, 4);
+    sz(RD * NMEL, 4); sz(RD * NMEL, 4); sz(5 * conv_rows * 512, 4);
+    need += 4096;
+    {
+        const void* before = tc.ws.p;
+        HIPCHK(e, tc.ws.ensure(need));
+        if (tc.ws.p != before) tacotron2_graphs_clear(e);
+    }
+    Arena A;
+    A.base = (char*)tc.ws.p;
+    A.cap = tc.ws.bytes;
+    float* d_masks = A.take<float>(n_masks);
+    float* d_pmfold = A.take<float>(try_persist ? (size_t)R * PERSIST_NPM : 1);
+    DecState* d_state = A.take<DecState>(1);
+    unsigned long long* d_xch = A.take<unsigned long long>(n_xch + 2);
+    int* d_pflags = A.take<int>(16);
+    float* d_hatt = A.take<float>(2 * B * ARNN);
+    float* d_catt = A.take<float>(B * ARNN);
+    float* d_hdec = A.take<float>(2 * B * DRNN);
+    float* d_cdec = A.take<float>(B * DRNN);
+    float* d_ctx = A.take<float>(B * enc);
+    float* d_p2 = A.take<float>(B * PRE);
+    float* d_q = A.take<float>(B * ATT);
+    float* d_frame = A.take<float>(B * NMEL);
+    float* d_energy = A.take<float>(R);
+    float* d_wprev = A.take<float>(R);
+    float* d_wcum = A.take<float>(R);
+    int* d_finished = A.take<int>(B);
+    int* d_lengths = A.take<int>(B);
+    int* d_mainatt = A.take<int>(2 * B);
+    float* d_decout = A.take<float>(RB * NMEL);
+    float* d_stop = A.take<float>(RB);
+    float* d_attn = A.take<float>(RB * Tin);
+    uint8_t* d_dmask = A.take<uint8_t>(RD);
+    float* d_xm = A.take<float>(RD * NMEL);
+    float* d_pa = A.take<float>(RD * 512);
+    float* d_pb = A.take<float>(RD * 512);
+    float* d_post = A.take<float>(RD * NMEL);
+    float* d_mel = A.take<float>(RD * NMEL);
+    float* d_convtmp = A.take<float>(5 * conv_rows * 512);
+    const size_t convtmp_n = 5 * conv_rows * 512;
+    if (A.off > A.cap) return set_err(e, TTS_HIP_ENOMEM, "tacotron2 workspace accounting error");
+    // all recurrent state, loop state, exchange area, histories and outputs of the real rows start at zero
+    const size_t zero_from = (char*)d_state - A.base, zero_mid = (char*)d_decout - A.base;
+    HIPCHK(e, hipMemsetAsync(A.base + zero_from, 0, zero_mid - zero_from, st));
+    HIPCHK(e, hipMemsetAsync(d_decout, 0, (size_t)RD * NMEL * 4, st));
+    HIPCHK(e, hipMemsetAsync(d_stop, 0, (size_t)RD * 4, st));
+    HIPCHK(e, hipMemsetAsync(d_attn, 0, (size_t)RD * Tin * 4, st));
+
+    // prenet dropout masks always travel through the workspace: a captured graph must not hold a caller's pointer
+    const hipMemcpyKind kin = mem == TTS_HIP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const float* masks_dev = nullptr;
+    if (prenet_masks) {
+        HIPCHK(e, hipMemcpyAsync(d_masks, prenet_masks, (size_t)RD * 2 * PRE * 4, kin, st));
+        masks_dev = d_masks;
     }
 
     // ---------------- decoder loop
@@ -1399,8 +1458,11 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
         timing_end(e);
         return TTS_HIP_OK;
     };
+    int rc;
     int host_steps = 0;
     bool persisted = false;
+    int bl_err = 0;
+    bool bl_checked = false;
     if (try_persist) {
         // Persistent weight-stationary loop (taco_persist.hip): the attention context is folded through the four linear maps
         // that consume it -- PM = memory x [W_att[:, ctx] | W_dec[:, ctx] | F[:, ctx] | P[:, ctx]] -- once per utterance.
@@ -1424,10 +1486,6 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
             g.ld0 = PERSIST_NPM;
             HIPCHK(e, gemm_small(g, 1, st));
         }
-        int bl_err = 0;
-        HIPCHK(e, hipMemcpyAsync(&bl_err, d_blerr, sizeof bl_err, hipMemcpyDeviceToHost, st));
-        HIPCHK(e, hipStreamSynchronize(st));
-        if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
         PersistCall pc{};
         pc.B = B; pc.Tin = Tin; pc.max_len = max_len; pc.early_stop = early_stop ? 1 : 0;
         pc.win_len = win_len; pc.win_off = win_offset; pc.half_w = half_w;
@@ -1440,24 +1498,49 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     }
     tc.last_path = persisted ? 1 : 0;
     if (!persisted) {
-        // chunks of CHUNK steps; after each chunk the host reads the loop state (one 24-byte copy)
+        // chunks of CHUNK steps; after each chunk the host reads the loop state (one 32-byte copy)
         DecState h{};
 #ifdef TTS_DEBUG_HOOKS
         const bool use_graph = !e->timing && getenv("TTS_HIP_NO_GRAPH") == nullptr;
 #else
         const bool use_graph = !e->timing;           // per-step HIP events (tts_hip_kernel_timing) cannot be captured
 #endif
-        hipGraph_t graph = nullptr;
         hipGraphExec_t gexec = nullptr;
         if (use_graph) {
-            HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int crc = TTS_HIP_OK;
-            for (int j = 0; j < CHUNK && crc == TTS_HIP_OK; ++j) crc = enqueue_step(j);
-            if (crc == TTS_HIP_OK) hipLaunchKernelGGL(advance_chunk_kernel, dim3(1), dim3(1), 0, st, d_state);
-            hipError_t ce = hipStreamEndCapture(st, &graph);
-            if (crc != TTS_HIP_OK) return crc;
-            HIPCHK(e, ce);
-            HIPCHK(e, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+            // The instantiated graph of a chunk is kept and replayed by every later call with the same shape bucket: the
+            // workspace and the encoded batch are stable allocations, so the 225 kernel nodes hold valid pointers.
+            const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, prenet_masks ? 1 : 0, win_len, win_offset,
+                                  half_w ? 1 : 0, try_persist ? 1 : 0};
+            auto it = tc.graphs.find(key);
+            if (it != tc.graphs.end()) {
+                gexec = it->second;
+            } else {
+                hipGraph_t graph = nullptr;
+                HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                int crc = TTS_HIP_OK;
+                for (int j = 0; j < CHUNK && crc == TTS_HIP_OK; ++j) crc = enqueue_step(j);
+                if (crc == TTS_HIP_OK) hipLaunchKernelGGL(advance_chunk_kernel, dim3(1), dim3(1), 0, st, d_state);
+                hipError_t ce = hipStreamEndCapture(st, &graph);
+                if (crc != TTS_HIP_OK || ce != hipSuccess) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    if (crc != TTS_HIP_OK) return crc;
+                    HIPCHK(e, ce);
+                }
+                hipError_t ie = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);             // the executable graph is self-contained
+                HIPCHK(e, ie);
+                constexpr size_t kMaxGraphs = 16;
+                if (tc.graph_order.size() >= kMaxGraphs) {
+                    auto old = tc.graphs.find(tc.graph_order.front());
+                    if (old != tc.graphs.end()) {
+                        (void)hipGraphExecDestroy(old->second);
+                        tc.graphs.erase(old);
+                    }
+                    tc.graph_order.erase(tc.graph_order.begin());
+                }
+                tc.graphs[key] = gexec;
+                tc.graph_order.push_back(key);
+            }
         }
         for (int t0 = 0; t0 < max_len; t0 += CHUNK) {
             if (use_graph) {
@@ -1468,19 +1551,13 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
                 hipLaunchKernelGGL(advance_chunk_kernel, dim3(1), dim3(1), 0, st, d_state);
             }
             HIPCHK(e, hipMemcpyAsync(&h, d_state, sizeof h, hipMemcpyDeviceToHost, st));
-            int bl_err = 0;
-            if (t0 == 0) HIPCHK(e, hipMemcpyAsync(&bl_err, d_blerr, sizeof bl_err, hipMemcpyDeviceToHost, st));
+            if (t0 == 0) HIPCHK(e, hipMemcpyAsync(&bl_err, en->bl_err, sizeof bl_err, hipMemcpyDeviceToHost, st));
             HIPCHK(e, hipStreamSynchronize(st));
-            if (bl_err) {
-                if (gexec) (void)hipGraphExecDestroy(gexec);
-                if (graph) (void)hipGraphDestroy(graph);
-                return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
-            }
+            bl_checked = true;
+            if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
             host_steps = h.steps_run;
             if (early_stop && h.n_fin[0] >= B) break;      // the last step of a chunk (odd j) wrote slot 0
         }
-        if (gexec) (void)hipGraphExecDestroy(gexec);
-        if (graph) (void)hipGraphDestroy(graph);
     }
 
     // ---------------- postnet + residual
@@ -1505,7 +1582,78 @@ static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B,
     if (stop_tokens) HIPCHK(e, hipMemcpyAsync(stop_tokens, d_stop, RD * 4, kout, st));
     if (attention) HIPCHK(e, hipMemcpyAsync(attention, d_attn, RD * Tin * 4, kout, st));
     if (lengths) HIPCHK(e, hipMemcpyAsync(lengths, d_lengths, (size_t)B * 4, kout, st));
+    if (!bl_checked) HIPCHK(e, hipMemcpyAsync(&bl_err, en->bl_err, sizeof bl_err, hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
+    if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
     if (steps_run) *steps_run = host_steps;
+    return TTS_HIP_OK;
+}
+
+static int tacotron2_infer_impl(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                                int max_len, int early_stop, const float* prenet_masks, int win_len,
+                                int win_offset, float* mel, float* decoder_output, float* stop_tokens,
+                                float* attention, int32_t* lengths, int32_t* steps_run, int mem, bool half_w) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (max_len <= 0) return set_err(e, TTS_HIP_EINVAL, "tacotron2_infer: bad argument");
+    Tacotron2Dev& tc = e->taco;
+    if (!tc.enc_cache) tc.enc_cache = new (std::nothrow) tts_hip_encoded();
+    if (!tc.enc_cache) return set_err(e, TTS_HIP_ENOMEM, "out of host memory");
+    int rc = tacotron2_encode_impl(e, tokens, B, Tin, speaker, mem, tc.enc_cache);
+    if (rc) return rc;
+    return tacotron2_decode_impl(e, tc.enc_cache, max_len, early_stop, prenet_masks, win_len, win_offset, mel,
+                                 decoder_output, stop_tokens, attention, lengths, steps_run, mem, half_w);
+}
+
+extern "C" int tts_hip_tacotron2_infer(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                                       int max_len, int early_stop, const float* prenet_masks, int win_len,
+                                       int win_offset, float* mel, float* decoder_output, float* stop_tokens,
+                                       float* attention, int32_t* lengths, int32_t* steps_run, int mem) {
+    return tacotron2_infer_impl(e, tokens, B, Tin, speaker, max_len, early_stop, prenet_masks, win_len, win_offset, mel,
+                                decoder_output, stop_tokens, attention, lengths, steps_run, mem, false);
+}
+
+extern "C" int tts_hip_tacotron2_infer_f16(tts_hip_engine* e, const int32_t* tokens, int B, int Tin,
+                                           const float* speaker, int max_len, int early_stop,
+                                           const float* prenet_masks, int win_len, int win_offset, float* mel,
+                                           float* decoder_output, float* stop_tokens, float* attention,
+                                           int32_t* lengths, int32_t* steps_run, int mem) {
+    return tacotron2_infer_impl(e, tokens, B, Tin, speaker, max_len, early_stop, prenet_masks, win_len, win_offset, mel,
+                                decoder_output, stop_tokens, attention, lengths, steps_run, mem, true);
+}
+
+extern "C" int tts_hip_tacotron2_encode(tts_hip_engine* e, const int32_t* tokens, int B, int Tin, const float* speaker,
+                                        int mem, void* stream, tts_hip_encoded** out) {
+    if (!e || !out) return TTS_HIP_EINVAL;
+    *out = nullptr;
+    tts_hip_encoded* en = new (std::nothrow) tts_hip_encoded();
+    if (!en) return set_err(e, TTS_HIP_ENOMEM, "out of host memory");
+    StreamScope scope(e, stream);
+    const int rc = tacotron2_encode_impl(e, tokens, B, Tin, speaker, mem, en);
+    if (rc) {
+        en->buf.release();
+        delete en;
+        return rc;
+    }
+    *out = en;
+    return TTS_HIP_OK;
+}
+
+extern "C" int tts_hip_tacotron2_decode(tts_hip_engine* e, const tts_hip_encoded* encoded, int max_len, int early_stop,
+                                        const float* prenet_masks, int win_len, int win_offset, int precision, float* mel,
+                                        float* decoder_output, float* stop_tokens, float* attention, int32_t* lengths,
+                                        int32_t* steps_run, int mem, void* stream) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (precision != 0 && precision != 1) return set_err(e, TTS_HIP_EINVAL, "tacotron2_decode: precision must be 0 (f32) or 1 (f16 weights)");
+    StreamScope scope(e, stream);
+    return tacotron2_decode_impl(e, encoded, max_len, early_stop, prenet_masks, win_len, win_offset, mel, decoder_output,
+                                 stop_tokens, attention, lengths, steps_run, mem, precision == 1);
+}
+
+extern "C" int tts_hip_encoded_free(tts_hip_engine* e, tts_hip_encoded* encoded) {
+    if (!e || !encoded) return TTS_HIP_EINVAL;
+    (void)hipSetDevice(e->device);
+    tacotron2_graphs_clear(e);                         // a cached graph may still point into this buffer
+    encoded->buf.release();                            // hipFree waits for work that still uses it
+    delete encoded;
     return TTS_HIP_OK;
 }

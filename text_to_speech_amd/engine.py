@@ -24,6 +24,27 @@ def _is_torch_cuda(x) -> bool:
     return hasattr(x, 'data_ptr') and hasattr(x, 'is_cuda') and bool(x.is_cuda)
 
 
+class EncodedBatch:
+    """Encoder output of one token batch, resident on the GPU (tts_hip_encoded).  Freed by `close()`, the garbage collector
+    or the engine's own teardown order (an engine must outlive its encoded batches)."""
+
+    def __init__(self, engine, handle, B, Tin, keep=(), on_device=False):
+        self.engine, self.handle, self.B, self.Tin, self.on_device = engine, handle, B, Tin, on_device
+        self._keep = keep                       # inputs of the still-running asynchronous encoder
+
+    def close(self):
+        if self.handle is not None and getattr(self.engine, '_h', None):
+            self.engine._lib.tts_hip_encoded_free(self.engine._h, self.handle)
+        self.handle = None
+        self._keep = ()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipEngine:
     def __init__(self, device: int = 0):
         self._lib = _lib.load_library()
@@ -59,6 +80,23 @@ class HipEngine:
         torch = self._torch()
         torch.cuda.current_stream(self.device).synchronize()
 
+    def _check_device(self, *tensors):
+        """Device tensors are passed by pointer: they must live on this engine's GPU (a pointer into another GPU's memory
+        would be read as garbage or fault)."""
+        for t in tensors:
+            if t is not None and _is_torch_cuda(t) and t.device.index != self.device:
+                raise ValueError(f'tensor on {t.device} passed to an engine on cuda:{self.device}')
+
+    def _order_after_torch(self, stream=None):
+        """Makes the work this call is about to enqueue wait for what torch has queued so far.  stream=None: the engine's
+        own (non-blocking) stream is used and the call returns after it drained, so torch's current stream on this device
+        is synchronized first (inputs may still be in flight there).  With a torch stream the engine call is enqueued on
+        that very stream: ordering is implicit and nothing is synchronized."""
+        if stream is None:
+            self._sync_torch()
+            return None
+        return ctypes.c_void_p(int(stream.cuda_stream))
+
     # ------------------------------------------------------------------ weights
     def set_tensor(self, name: str, array) -> None:
         a = np.ascontiguousarray(array, dtype=np.float32)
@@ -80,9 +118,10 @@ class HipEngine:
         return bool(self._lib.tts_hip_has_model(self._h, model.encode()))
 
     # ------------------------------------------------------------------ WaveGlow
-    def waveglow_infer(self, mel, z=None, sigma: float = 1.0, precision: str = 'f32'):
+    def waveglow_infer(self, mel, z=None, sigma: float = 1.0, precision: str = 'f32', stream=None):
         """mel [B, T, 80] (+ optional z [B, T*32, 8]) -> audio [B, T*256].  precision: 'f32' (exact fp32 MFMA), 'f16x3'
-        (split fp16: fp32-class accuracy, ~3x faster) or 'f16' (fp16 operands)."""
+        (split fp16: fp32-class accuracy, ~3x faster) or 'f16' (fp16 operands).  `stream` (a torch.cuda.Stream, device
+        tensors only): enqueue on that stream and return without waiting (tts_hip_waveglow_infer_async)."""
         fns = {'f32': self._lib.tts_hip_waveglow_infer, 'f16': self._lib.tts_hip_waveglow_infer_f16,
                'f16x3': self._lib.tts_hip_waveglow_infer_f16x3}
         if precision not in fns:
@@ -100,11 +139,21 @@ class HipEngine:
                 if tuple(z.shape) != (B, T * 32, 8):
                     raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {tuple(z.shape)}')
                 zp = ctypes.c_void_p(z.data_ptr())
+            self._check_device(mel, z)
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    out = torch.empty((B, T * 256), dtype=torch.float32, device=mel.device)
+                self._check(self._lib.tts_hip_waveglow_infer_async(
+                    self._h, ctypes.c_void_p(mel.data_ptr()), B, T, zp, float(sigma), ctypes.c_void_p(out.data_ptr()),
+                    {'f32': 0, 'f16': 1, 'f16x3': 2}[precision], self._order_after_torch(stream)), 'waveglow_infer_async')
+                return out
             out = torch.empty((B, T * 256), dtype=torch.float32, device=mel.device)
-            self._sync_torch()
+            self._order_after_torch()
             self._check(fn(self._h, ctypes.c_void_p(mel.data_ptr()), B, T, zp, float(sigma),
                            ctypes.c_void_p(out.data_ptr()), MEM_DEVICE), 'waveglow_infer')
             return out
+        if stream is not None:
+            raise ValueError('stream= needs device tensors')
         mel = np.ascontiguousarray(mel, dtype=np.float32)
         if mel.ndim != 3 or mel.shape[2] != 80:
             raise ValueError(f'mel must be [B, T, 80], got {mel.shape}')
@@ -166,7 +215,8 @@ class HipEngine:
         lengths = mk((B,), i32)
         steps = ctypes.c_int32(0)
         if dev:
-            self._sync_torch()
+            self._check_device(tok, speaker, prenet_masks)
+            self._order_after_torch()
         win = int(attn_mask_win_len) if attn_mask_win_len is not None else 0
         self._check(fn(
             self._h, ptr(tok), B, Tin, ptr(speaker), max_len, 1 if early_stopping else 0, ptr(prenet_masks),
@@ -176,6 +226,77 @@ class HipEngine:
                                        lengths=lengths)
         self.last_steps = int(steps.value)
         return out
+
+    # ------------------------------------------------------------------ Tacotron2 in two calls
+    def tacotron2_encode(self, tokens, speaker=None, stream=None):
+        """tokens int32 [B, Tin] (+ speaker [B, E]) -> `EncodedBatch` (the encoder's output, kept on the GPU).  Asynchronous:
+        the encoder is only enqueued (on `stream`, a torch.cuda.Stream, or on the engine's own stream)."""
+        dev = _is_torch_cuda(tokens)
+        if dev:
+            torch = self._torch()
+            tok = tokens.to(torch.int32).contiguous()
+            spk = None if speaker is None else speaker.to(device=tok.device, dtype=torch.float32).contiguous()
+            self._check_device(tok, spk)
+            ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+            sp = self._order_after_torch(stream)
+        else:
+            if stream is not None:
+                raise ValueError('stream= needs device tensors')
+            tok = np.ascontiguousarray(tokens, dtype=np.int32)
+            spk = None if speaker is None else np.ascontiguousarray(speaker, dtype=np.float32)
+            ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+            sp = None
+        if tok.ndim != 2:
+            raise ValueError(f'tokens must be [B, Tin], got {tuple(tok.shape)}')
+        h = ctypes.c_void_p()
+        self._check(self._lib.tts_hip_tacotron2_encode(self._h, ptr(tok), int(tok.shape[0]), int(tok.shape[1]), ptr(spk),
+                                                       MEM_DEVICE if dev else MEM_HOST, sp, ctypes.byref(h)),
+                    'tacotron2_encode')
+        return EncodedBatch(self, h, int(tok.shape[0]), int(tok.shape[1]), keep=(tok, spk), on_device=dev)
+
+    def tacotron2_decode(self, encoded, max_len: int = 1000, early_stopping: bool = True, prenet_masks=None,
+                         attn_mask_win_len=None, attn_mask_offset: int = 0, want_attention=True, precision: str = 'f32',
+                         stream=None):
+        """Decoder loop + postnet on an `EncodedBatch`; may be called repeatedly (new dropout masks, other `max_len`).
+        Returns after `stream` (or the engine's stream) has drained: the loop's length is decided on the GPU."""
+        if precision not in ('f32', 'f16'):
+            raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
+        if encoded.engine is not self or encoded.handle is None:
+            raise ValueError('this EncodedBatch belongs to another engine or was freed')
+        B, Tin, dev = encoded.B, encoded.Tin, encoded.on_device
+        max_len = int(max_len)
+        if max_len <= 0:
+            raise ValueError('max_len must be positive')
+        if dev:
+            torch = self._torch()
+            device = torch.device('cuda', self.device)
+            mk = lambda shape, dt=None: torch.zeros(shape, dtype=dt or torch.float32, device=device)
+            ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+            if prenet_masks is not None:
+                prenet_masks = prenet_masks.to(device=device, dtype=torch.float32).contiguous()
+                self._check_device(prenet_masks)
+            i32 = torch.int32
+        else:
+            mk = lambda shape, dt=None: np.zeros(shape, dtype=dt or np.float32)
+            ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+            if prenet_masks is not None:
+                prenet_masks = np.ascontiguousarray(prenet_masks, dtype=np.float32)
+            i32 = np.int32
+        if prenet_masks is not None and tuple(prenet_masks.shape) != (B, max_len, 2, 256):
+            raise ValueError(f'prenet_masks must be [B, max_len, 2, 256], got {tuple(prenet_masks.shape)}')
+        mel, dec, stop = mk((B, max_len, 80)), mk((B, max_len, 80)), mk((B, max_len))
+        attn = mk((B, max_len, Tin)) if want_attention else None
+        lengths = mk((B,), i32)
+        steps = ctypes.c_int32(0)
+        sp = self._order_after_torch(stream) if dev else None
+        win = int(attn_mask_win_len) if attn_mask_win_len is not None else 0
+        self._check(self._lib.tts_hip_tacotron2_decode(
+            self._h, encoded.handle, max_len, 1 if early_stopping else 0, ptr(prenet_masks), win, int(attn_mask_offset),
+            1 if precision == 'f16' else 0, ptr(mel), ptr(dec), ptr(stop), ptr(attn), ptr(lengths),
+            ctypes.cast(ctypes.byref(steps), ctypes.c_void_p), MEM_DEVICE if dev else MEM_HOST, sp), 'tacotron2_decode')
+        self.last_steps = int(steps.value)
+        return Tacotron2InferenceOutput(decoder_output=dec, mel=mel, stop_tokens=stop, attention_weights=attn,
+                                        lengths=lengths)
 
     def set_decoder_mode(self, mode: str) -> None:
         """'persistent' (default: one weight-stationary cooperative kernel for the whole decoder loop when the call shape
@@ -191,8 +312,9 @@ class HipEngine:
         return {1: 'persistent', 0: 'graph'}.get(self._lib.tts_hip_last_decoder_mode(self._h), 'none')
 
     # ------------------------------------------------------------------ mel-STFT
-    def mel_stft(self, audio):
-        """audio [N] or [B, N] -> mel [B, N // 256 + 1, 80] (the reference's TacotronSTFT()(audio))."""
+    def mel_stft(self, audio, stream=None):
+        """audio [N] or [B, N] -> mel [B, N // 256 + 1, 80] (the reference's TacotronSTFT()(audio)).  `stream` (torch.cuda.Stream,
+        device tensors only): enqueue there and return without waiting."""
         if _is_torch_cuda(audio):
             torch = self._torch()
             a = audio.to(torch.float32)
@@ -202,11 +324,21 @@ class HipEngine:
                 a = torch.nn.functional.pad(a, (0, 1024 - a.shape[1]))
             a = a.contiguous()
             B, N = int(a.shape[0]), int(a.shape[1])
+            self._check_device(a)
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    out = torch.empty((B, N // 256 + 1, 80), dtype=torch.float32, device=a.device)
+                self._check(self._lib.tts_hip_mel_stft_async(self._h, ctypes.c_void_p(a.data_ptr()), B, N,
+                                                             ctypes.c_void_p(out.data_ptr()), self._order_after_torch(stream)),
+                            'mel_stft_async')
+                return out
             out = torch.empty((B, N // 256 + 1, 80), dtype=torch.float32, device=a.device)
-            self._sync_torch()
+            self._order_after_torch()
             self._check(self._lib.tts_hip_mel_stft(self._h, ctypes.c_void_p(a.data_ptr()), B, N,
                                                    ctypes.c_void_p(out.data_ptr()), MEM_DEVICE), 'mel_stft')
             return out
+        if stream is not None:
+            raise ValueError('stream= needs device tensors')
         a = np.asarray(audio, dtype=np.float32)
         if a.ndim == 1:
             a = a[None]

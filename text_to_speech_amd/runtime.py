@@ -96,6 +96,10 @@ class HipRuntime(Runtime):
         self.synthesizer_precision = kwargs.get('synthesizer_precision', 'f32')
         if self.synthesizer_precision not in ('f32', 'f16'):
             raise ValueError(f"synthesizer_precision must be 'f32' or 'f16', got {self.synthesizer_precision!r}")
+        # The reference retries a sentence up to `max_trial` times with fresh prenet dropout (models/tts/tacotron2.py:160-179):
+        # the encoder output of the last token batch is kept so that a retry only re-runs the decoder loop.
+        self._encoded = None                     # (key, EncodedBatch)
+        self.encoder_reuses = 0
 
     @staticmethod
     def load_engine(path, device=0, speaker_embedding_dim=0, **kwargs):
@@ -161,9 +165,23 @@ class HipRuntime(Runtime):
             if dev:
                 import torch
                 prenet_masks = torch.from_numpy(prenet_masks).to(tokens.device)
-        return self.engine.tacotron2_infer(
-            tokens if dev else tok_np, speaker=speaker, max_len=max_len, early_stopping=bool(early_stopping),
-            prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
+        spk_np = None if speaker is None else (speaker.detach().cpu().numpy() if _is_torch_cuda(speaker) else np.asarray(speaker))
+        key = (tok_np.shape, tok_np.astype(np.int32).tobytes(), None if spk_np is None else spk_np.astype(np.float32).tobytes(),
+               bool(dev))
+        if self._encoded is not None and self._encoded[0] == key and hasattr(self.engine, 'tacotron2_decode'):
+            self.encoder_reuses += 1
+        elif hasattr(self.engine, 'tacotron2_encode'):
+            if self._encoded is not None:
+                self._encoded[1].close()
+            self._encoded = (key, self.engine.tacotron2_encode(tokens if dev else tok_np, speaker=speaker))
+        else:                                                    # an engine object without the split entry points
+            return self.engine.tacotron2_infer(
+                tokens if dev else tok_np, speaker=speaker, max_len=max_len, early_stopping=bool(early_stopping),
+                prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
+                precision=precision or self.synthesizer_precision)
+        return self.engine.tacotron2_decode(
+            self._encoded[1], max_len=max_len, early_stopping=bool(early_stopping), prenet_masks=prenet_masks,
+            attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
             precision=precision or self.synthesizer_precision)
 
     # ------------------------------------------------------------------ WaveGlow.infer (waveglow_arch.py:244-306)
