@@ -20,6 +20,32 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
         python3 "$B" --steps 1 --warmup 0 --cpu-frames 0 --no-extra --no-kernel-timing > /dev/null 2> "$out/pmc_$name.log"
 done
 fi
+# 2b. the fp16 / split-fp16 in-layer kernels: kernel stats and one PMC pass each (bytes, MFMA busy, active clock)
+for prec in f16 f16x3; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$prec" -o "$prec" -- \
+        python3 "$root/scripts/x3_time.py" $prec > "$out/${prec}_time.txt" 2> "$out/stats_$prec.log"
+    for pmc in "FETCH_SIZE WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"; do
+        name="$(echo "$pmc" | cut -d' ' -f1)"
+        timeout -k 10 300 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc_${prec}_$name" -o "$prec" -- \
+            python3 "$root/scripts/x3_time.py" $prec > /dev/null 2> "$out/pmc_${prec}_$name.log"
+    done
+done
+if [[ -z "${WITH_LEGACY_F16:-}" ]]; then
+# 4. Tacotron2 decoder: batch 1 = persistent weight-stationary kernel, batch 8 = per-step graph; plus batch 1 on the graph path
+for spec in "1 256 f32 persistent" "8 256 f32 persistent" "1 256 f32 graph"; do
+    set -- $spec
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/taco_b$1_$4" -o taco -- \
+        python3 "$root/scripts/run_taco.py" $1 $2 $3 $4 > "$out/taco_b$1_$4.txt" 2> "$out/taco_b$1_$4.log"
+done
+# 5. HBM/L2 fetch bytes of the decoder kernels, batch 1 (persistent: weights are read once per CALL) and batch 8 (graph)
+for spec in "1 64 f32 persistent" "8 64 f32 persistent"; do
+    set -- $spec
+    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/taco_pmc_b$1" -o taco -- \
+        python3 "$root/scripts/run_taco.py" $1 $2 $3 $4 > /dev/null 2> "$out/taco_pmc_b$1.log"
+done
+find "$out" -name "*.csv" | sort
+exit 0
+fi
 # 3. fp16 mode kernel stats (same shape)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_f16" -o f16 -- \
     python3 "$root/scripts/f16_time.py" f16 > "$out/f16_time.txt" 2> "$out/stats_f16.log"

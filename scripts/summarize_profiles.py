@@ -30,8 +30,12 @@ def copy_stats(sub, name):
 
 copy_stats('stats', f'{tag}_bench_kernel_stats.csv')
 copy_stats('stats_f16', f'{tag}_waveglow_f16_kernel_stats.csv')
+copy_stats('stats_f16x3', f'{tag}_waveglow_f16x3_kernel_stats.csv')
 for b in (1, 8):
     copy_stats(f'taco_b{b}', f'{tag}_tacotron2_b{b}_kernel_stats.csv')
+copy_stats('taco_b1_persistent', f'{tag}_tacotron2_b1_persistent_kernel_stats.csv')
+copy_stats('taco_b8_persistent', f'{tag}_tacotron2_b8_graph_kernel_stats.csv')        # batch 8 falls back to the per-step graph
+copy_stats('taco_b1_graph', f'{tag}_tacotron2_b1_graph_kernel_stats.csv')
 bj = os.path.join(src, 'bench_under_rocprof.json')
 if os.path.exists(bj):
     lines = [l for l in open(bj) if l.startswith('{')]
@@ -74,10 +78,41 @@ for kn, cs in merged.items():
     if 'SQ_WAIT_ANY' in cs and 'SQ_WAVE_CYCLES' in cs:
         e['wait_any_frac'] = sum(cs['SQ_WAIT_ANY']) / max(1.0, sum(cs['SQ_WAVE_CYCLES']))
     summary['kernels'][kn[:120]] = e
-taco = counters('taco_pmc_b1')
-if taco:
-    summary['tacotron2_b1_fetch_KB_mean'] = {kn[:90]: sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE'])
-                                             for kn, cs in taco.items() if 'FETCH_SIZE' in cs and len(cs['FETCH_SIZE']) >= 32}
+for b in (1, 8):
+    taco = counters(f'taco_pmc_b{b}')
+    if taco:
+        summary[f'tacotron2_b{b}_fetch_KB_mean'] = {
+            kn[:90]: {'mean_KB': sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE']), 'launches': len(cs['FETCH_SIZE'])}
+            for kn, cs in taco.items() if 'FETCH_SIZE' in cs and ('persist' in kn or len(cs['FETCH_SIZE']) >= 32)}
+# fp16 / split-fp16 WaveGlow kernels: bytes, MFMA busy fraction and effective clock of every GEMM / end-fold kernel
+for prec in ('f16', 'f16x3'):
+    m = {}
+    for sub in (f'pmc_{prec}_FETCH_SIZE', f'pmc_{prec}_SQ_VALU_MFMA_BUSY_CYCLES'):
+        for kn, cs in counters(sub).items():
+            for cn, vals in cs.items():
+                m.setdefault(kn, {})[cn] = vals
+    stats = {}
+    f = find(f'stats_{prec}', '*kernel_stats.csv')
+    if f:
+        for r in csv.DictReader(open(f)):
+            stats[r['Name']] = float(r['AverageNs'])
+    outp = {}
+    for kn, cs in m.items():
+        if 'gemm_f32_kernel' not in kn and 'wn_' not in kn:
+            continue
+        e = {'launches': max(len(v) for v in cs.values())}
+        for cn, vals in cs.items():
+            e[cn + '_mean'] = sum(vals) / len(vals)
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and 'GRBM_GUI_ACTIVE' in cs:
+            busy = sum(cs['SQ_VALU_MFMA_BUSY_CYCLES']) / len(cs['SQ_VALU_MFMA_BUSY_CYCLES'])
+            gui = sum(cs['GRBM_GUI_ACTIVE']) / len(cs['GRBM_GUI_ACTIVE'])
+            e['mfma_busy_frac'] = busy / (1024.0 * gui / 8.0)
+            if kn in stats:
+                e['avg_ns_unprofiled_pass'] = stats[kn]
+                e['effective_clock_GHz'] = (gui / 8.0) / stats[kn]
+        outp[kn[:140]] = e
+    if outp:
+        summary[f'waveglow_{prec}_kernels'] = outp
 json.dump(summary, open(os.path.join(dst, f'{tag}_pmc_counters.json'), 'w'), indent=1)
 print('wrote', f'{tag}_pmc_counters.json')
 for kn, e in summary['kernels'].items():

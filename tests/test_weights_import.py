@@ -76,3 +76,77 @@ def test_cli_writes_loadable_ttsw(tmp_path, taco_cfg):
     weights_import.main(['--tacotron2', str(ck), '-o', str(out)])
     back = weights.load_ttsw(out)
     assert set(back) == set(w) and np.allclose(back['tacotron2/decoder/gate_output/bias'], w['tacotron2/decoder/gate_output/bias'])
+
+
+def _keras_paths(manifest_name):
+    """A plausible Keras 3 `variable.path` for a manifest tensor, built from the layer names of the reference source
+    (tacotron2_arch.py:80-107,168,248,299,347,359-361,503-508; location_sensitive_attention.py:36-73; waveglow_arch.py:58-87,
+    197,213,222; invertible_conv.py:32) with the wrappers Keras adds (Bidirectional -> forward_lstm / backward_lstm +
+    lstm_cell, StackedRNNCells, the functional encoder model)."""
+    parts = manifest_name.split('/')
+    if parts[0] == 'waveglow':
+        if parts[1].startswith('invertible_conv'):
+            return f'wave_glow/{parts[1]}/conv/kernel'
+        return 'wave_glow/' + '/'.join(parts[1:])
+    var = parts[-1]
+    if manifest_name == 'tacotron2/encoder/embeddings':
+        return 'encoder/encoder_embeddings/embeddings'
+    if parts[1] == 'encoder' and parts[2] == 'bi_lstm':
+        return f'encoder/bidirectional/{parts[3]}_lstm/lstm_cell/{var}'
+    if parts[1] in ('encoder', 'postnet'):
+        return f'{parts[1]}/{parts[2]}/{var}'
+    if parts[2] == 'prenet':
+        return f'decoder/prenet/{parts[3]}/kernel'
+    if parts[2] == 'lsa':
+        inner = 'location_layer/' if parts[3].startswith('location') else ''
+        return f'decoder/decoder_cell/location_sensitive_attention/{inner}{parts[3]}/kernel'
+    if parts[2] == 'attention_rnn':
+        return f'decoder/decoder_cell/attention_rnn/{var}'
+    if parts[2] == 'decoder_rnn':
+        return f'decoder/decoder_cell/decoder_rnn/cell_0/{var}'
+    return f'decoder/{parts[2]}/{var}'
+
+
+def test_keras_variable_paths_map_onto_the_manifest(taco_cfg, wg_cfg):
+    """Step 2 of the Keras checkpoint import: renaming + shape check; extra variables are ignored, clashes and gaps raise."""
+    import pytest
+    from text_to_speech_amd import weights, weights_import
+    from text_to_speech_amd.config import Tacotron2Config, WaveGlowConfig
+    cfg = Tacotron2Config(speaker_embedding_dim=256)
+    w = weights.synth_tacotron2(cfg, seed=2)
+    named = {_keras_paths(k): v for k, v in w.items()}
+    assert len(named) == len(w)
+    named['decoder/decoder_cell/attention_rnn/kernel:0'] = named.pop('decoder/decoder_cell/attention_rnn/kernel')   # TF-style suffix
+    named['adam/decoder_gate_output_kernel_momentum'] = np.zeros((3,), np.float32)       # not an inference variable
+    named['encoder/speaker_embedding/embeddings'] = np.zeros((10, 256), np.float32)      # speaker table: not in the manifest
+    back = weights_import.from_keras_variables(named, 'tacotron2', cfg)
+    assert list(back) == list(w) and all(np.array_equal(back[k], w[k]) for k in w)
+    small = WaveGlowConfig(n_channels=8, n_layers=2)
+    ww = weights.synth_waveglow(small, seed=3)
+    back = weights_import.from_keras_variables({_keras_paths(k): v for k, v in ww.items()}, 'waveglow', small)
+    assert list(back) == list(ww) and all(np.array_equal(back[k], ww[k]) for k in ww)
+    # a missing tensor and a wrong shape are errors, with the tensor named
+    broken = dict(named)
+    broken.pop('decoder/gate_output/bias')
+    with pytest.raises(KeyError, match='gate_output/bias'):
+        weights_import.from_keras_variables(broken, 'tacotron2', cfg)
+    broken = dict(named)
+    broken['decoder/gate_output/bias'] = np.zeros((2,), np.float32)
+    with pytest.raises(ValueError, match='gate_output/bias'):
+        weights_import.from_keras_variables(broken, 'tacotron2', cfg)
+    clash = dict(named)
+    clash['other_scope/decoder/gate_output/bias'] = np.zeros((1,), np.float32)
+    with pytest.raises(ValueError, match='both map'):
+        weights_import.from_keras_variables(clash, 'tacotron2', cfg)
+
+
+def test_keras_import_cli_roundtrip(tmp_path, taco_cfg):
+    from safetensors.numpy import save_file
+    from text_to_speech_amd import weights, weights_import
+    w = weights.synth_tacotron2(taco_cfg, seed=4)
+    src = tmp_path / 'vars.safetensors'
+    save_file({_keras_paths(k): v for k, v in w.items()}, str(src))
+    out = tmp_path / 'model.ttsw'
+    weights_import.main(['--keras-tacotron2', str(src), '-o', str(out)])
+    back = weights.load_ttsw(out)
+    assert list(back) == list(w) and all(np.array_equal(back[k], w[k]) for k in w)

@@ -127,6 +127,93 @@ def from_nvidia_waveglow(state_dict, cfg: WaveGlowConfig = WaveGlowConfig()):
     return _checked(o, waveglow_manifest(cfg))
 
 
+# ---- Keras checkpoints (the reference's own `.weights.h5` files) ------------------------------------------------------------
+# The reference stores its models as Keras 3 `ckpt-XXXX.weights.h5` (custom_train_objects/checkpoint_manager.py:148-215).
+# HDF5 cannot be read here (no h5py), and the H5 group names depend on the Keras version, so the supported route is a
+# two-step one:  (1) where the reference runs (Keras + h5py installed), `scripts/export_keras_weights.py <model name>`
+# restores the model with the reference's own code and writes `{variable.path: value}` to a `.safetensors` file;
+# (2) here, `from_keras_variables` maps those variable paths onto the engine's manifest.  Keras layouts ARE the manifest's
+# layouts (Dense [in, out], Conv1D [k, in, out], Conv1DTranspose [k, out, in], LSTM kernel / recurrent_kernel / bias with
+# gates i, f, c, o -- models/weights_converter.py:252-322 is only needed for torch checkpoints), so this is renaming plus a
+# shape check.  Layer names come from the reference source: architectures/tacotron2_arch.py:80-107,168,248,299,347,359-361,
+# 503-508, architectures/layers/location_sensitive_attention.py:36-59, architectures/waveglow_arch.py:58-87,197,213,222,
+# architectures/layers/invertible_conv.py:32.
+_KERAS_VAR = {'kernel', 'recurrent_kernel', 'bias', 'gamma', 'beta', 'moving_mean', 'moving_variance', 'embeddings'}
+
+
+def _keras_target(path: str, model: str):
+    """Manifest name for one Keras variable path, or None if the variable is not part of the inference path."""
+    import re
+    parts = [p for p in path.replace(':0', '').split('/') if p]
+    if not parts or parts[-1] not in _KERAS_VAR:
+        return None
+    var, scope = parts[-1], parts[:-1]
+    has = lambda name: any(p == name for p in scope)
+    find = lambda pat: next((m for m in (re.fullmatch(pat, p) for p in scope) if m), None)
+    if model == 'waveglow':
+        if has('upsample'):
+            return f'waveglow/upsample/{var}'
+        inv = find(r'invertible_conv-(\d+)')
+        if inv and var == 'kernel':
+            return f'waveglow/invertible_conv-{inv.group(1)}/conv/kernel'
+        blk = find(r'block-(\d+)')
+        if blk:
+            for pat in (r'start_conv', r'end_conv', r'in_conv-\d+', r'cond_layer-\d+', r'res_skip_conv-\d+'):
+                hit = find(pat)
+                if hit:
+                    return f'waveglow/block-{blk.group(1)}/{hit.group(0)}/{var}'
+        return None
+    # tacotron2
+    if var == 'embeddings':
+        return 'tacotron2/encoder/embeddings' if not has('speaker_embedding') else None
+    conv, norm = find(r'conv_(\d+)'), find(r'norm_(\d+)')
+    section = 'postnet' if has('postnet') else 'encoder' if has('encoder') else None
+    if section and conv and var in ('kernel', 'bias'):
+        return f'tacotron2/{section}/conv_{conv.group(1)}/{var}'
+    if section and norm:
+        return f'tacotron2/{section}/norm_{norm.group(1)}/{var}'
+    if var in ('kernel', 'recurrent_kernel', 'bias'):
+        direction = next((d for d in ('forward', 'backward') if any(p.startswith(d) for p in scope)), None)
+        if direction:
+            return f'tacotron2/encoder/bi_lstm/{direction}/{var}'
+        if has('attention_rnn'):
+            return f'tacotron2/decoder/attention_rnn/{var}'
+        cell = find(r'cell_(\d+)')
+        if cell and cell.group(1) == '0':
+            return f'tacotron2/decoder/decoder_rnn/cell_0/{var}'
+    layer = find(r'layer_(\d+)')
+    if has('prenet') and layer and var == 'kernel':
+        return f'tacotron2/decoder/prenet/layer_{layer.group(1)}/kernel'
+    for name in ('query_layer', 'memory_layer', 'value_layer', 'location_conv', 'location_dense'):
+        if has(name) and var == 'kernel':
+            return f'tacotron2/decoder/lsa/{name}/kernel'
+    for name in ('linear_projection', 'gate_output'):
+        if has(name):
+            return f'tacotron2/decoder/{name}/{var}'
+    return None
+
+
+def from_keras_variables(named, model: str, cfg=None):
+    """{Keras variable path: array} (as written by scripts/export_keras_weights.py) -> manifest tensors of `model`
+    ('tacotron2' | 'waveglow').  Every manifest tensor must be matched exactly once with the right shape; variables that
+    do not belong to inference (optimizer slots, a speaker-embedding table, ...) are ignored."""
+    if model == 'tacotron2':
+        manifest = tacotron2_manifest(cfg or Tacotron2Config())
+    elif model == 'waveglow':
+        manifest = waveglow_manifest(cfg or WaveGlowConfig())
+    else:
+        raise ValueError(f"model must be 'tacotron2' or 'waveglow', got {model!r}")
+    out, origin = {}, {}
+    for path, value in named.items():
+        target = _keras_target(path, model)
+        if target is None or target not in manifest:
+            continue
+        if target in out:
+            raise ValueError(f'{origin[target]!r} and {path!r} both map to {target}')
+        out[target], origin[target] = _np(value), path
+    return _checked(out, manifest)
+
+
 def _checked(tensors, manifest):
     out = OrderedDict()
     for name, shape in manifest.items():
@@ -233,10 +320,21 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
     ap.add_argument('--tacotron2', help='NVIDIA Tacotron2 checkpoint (.pt)')
     ap.add_argument('--waveglow', help='NVIDIA WaveGlow checkpoint (.pt, weight norm allowed)')
+    ap.add_argument('--keras-tacotron2', help='Keras variables of the Tacotron2 model (scripts/export_keras_weights.py output)')
+    ap.add_argument('--keras-waveglow', help='Keras variables of the WaveGlow model (scripts/export_keras_weights.py output)')
+    ap.add_argument('--speaker-embedding-dim', type=int, default=0, help='256 for the SV2TTS Tacotron2')
     ap.add_argument('-o', '--output', required=True, help='TTSW file to write')
     args = ap.parse_args(argv)
-    import torch
     tensors = OrderedDict()
+    if args.keras_tacotron2 or args.keras_waveglow:
+        from safetensors.numpy import load_file
+        if args.keras_tacotron2:
+            tensors.update(from_keras_variables(load_file(args.keras_tacotron2), 'tacotron2',
+                                                Tacotron2Config(speaker_embedding_dim=args.speaker_embedding_dim)))
+        if args.keras_waveglow:
+            tensors.update(from_keras_variables(load_file(args.keras_waveglow), 'waveglow'))
+    if args.tacotron2 or args.waveglow:
+        import torch
     if args.tacotron2:
         ck = torch.load(args.tacotron2, map_location='cpu')
         tensors.update(from_nvidia_tacotron2(ck.get('state_dict', ck)))
