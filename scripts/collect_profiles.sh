@@ -2,7 +2,7 @@
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   scripts/collect_profiles.sh <tag>        e.g. r01b
 # Outputs land in gpurun_out/prof_<tag>/ ; scripts/summarize_profiles.py turns them into the files kept under profiles/.
-set -euo pipefail
+set -uo pipefail   # a profiled process that crashes at exit (seen: SIGSEGV in teardown after the outputs were written) must not stop the collection
 tag="${1:-r01}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out/prof_$tag"
@@ -22,12 +22,14 @@ done
 fi
 # 2b. the fp16 / split-fp16 in-layer kernels: kernel stats and one PMC pass each (bytes, MFMA busy, active clock)
 for prec in f16 f16x3; do
+    [[ -n "${SKIP_X3:-}" ]] && continue
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$prec" -o "$prec" -- \
         python3 "$root/scripts/x3_time.py" $prec > "$out/${prec}_time.txt" 2> "$out/stats_$prec.log"
-    for pmc in "FETCH_SIZE WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"; do
+    # (FETCH_SIZE and WRITE_SIZE do not fit one pass: "Request exceeds the capabilities of the hardware to collect")
+    for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"; do
         name="$(echo "$pmc" | cut -d' ' -f1)"
         timeout -k 10 300 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc_${prec}_$name" -o "$prec" -- \
-            python3 "$root/scripts/x3_time.py" $prec > /dev/null 2> "$out/pmc_${prec}_$name.log"
+            python3 "$root/scripts/x3_time.py" $prec > /dev/null 2> "$out/pmc_${prec}_$name.log" || echo "pmc pass $prec $name failed"
     done
 done
 if [[ -z "${WITH_LEGACY_F16:-}" ]]; then

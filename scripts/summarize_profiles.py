@@ -87,7 +87,7 @@ for b in (1, 8):
 # fp16 / split-fp16 WaveGlow kernels: bytes, MFMA busy fraction and effective clock of every GEMM / end-fold kernel
 for prec in ('f16', 'f16x3'):
     m = {}
-    for sub in (f'pmc_{prec}_FETCH_SIZE', f'pmc_{prec}_SQ_VALU_MFMA_BUSY_CYCLES'):
+    for sub in (f'pmc_{prec}_FETCH_SIZE', f'pmc_{prec}_WRITE_SIZE', f'pmc_{prec}_SQ_VALU_MFMA_BUSY_CYCLES'):
         for kn, cs in counters(sub).items():
             for cn, vals in cs.items():
                 m.setdefault(kn, {})[cn] = vals
