@@ -98,3 +98,37 @@ def test_runtime_retry_reuses_the_encoder(gpu_engine, taco_weights, taco_cfg):
     assert rt.encoder_reuses == 2 and np.abs(c.mel - ref.mel).max() <= 1e-3
     rt(_tokens(1, 30, [30], seed=9), max_length=12, early_stopping=False, deterministic=True)
     assert rt.encoder_reuses == 2
+
+
+def test_two_handles_decoding_at_once_share_the_gpu_correctly(gpu_engine, taco_weights):
+    """The persistent decoder needs every CU: when two handles decode at the same time (two threads, two HIP streams), the
+    second grid waits at its start-up rendezvous until the first has finished -- or gives up cleanly and runs the per-step
+    graph.  Either way both results must equal the ones computed alone."""
+    import threading
+    from text_to_speech_amd.engine import HipEngine
+    eng2 = HipEngine(0)
+    eng2.load_state(taco_weights)
+    eng2.finalize()
+    try:
+        toks = [_tokens(1, 60, [60], seed=21), _tokens(2, 45, [45, 30], seed=22)]
+        engines = [gpu_engine, eng2]
+        alone = [e.tacotron2_infer(t, max_len=300, early_stopping=False, want_attention=False) for e, t in zip(engines, toks)]
+        for _ in range(3):
+            res, modes = [None, None], [None, None]
+
+            def run(i):
+                res[i] = engines[i].tacotron2_infer(toks[i], max_len=300, early_stopping=False, want_attention=False)
+                modes[i] = engines[i].last_decoder_mode
+
+            th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            print('concurrent decoder paths:', modes)
+            for i in range(2):
+                # a fallback to the per-step graph differs by fp32 re-association only
+                assert np.abs(res[i].mel - alone[i].mel).max() <= 1e-4, (i, modes)
+                assert np.array_equal(res[i].lengths, alone[i].lengths)
+    finally:
+        eng2.close()

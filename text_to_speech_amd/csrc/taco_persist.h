@@ -32,8 +32,9 @@ size_t persist_xch_u64(int B, int Tin);
 // true if this call shape can run on the persistent kernel on the engine's device (batch, LDS footprint, CU count)
 bool persist_applicable(const tts_hip_engine* e, int B, int Tin);
 // Runs the whole decoder loop (all steps, device-side early stop) in ONE cooperative launch on `st`.
-// Returns TTS_HIP_OK and *steps_run, or 1 if the blocks could not all become resident (nothing was modified: the caller
-// falls back to the per-step graph), or a negative TTS_HIP_E* code.  Synchronizes `st`.
+// Returns TTS_HIP_OK and *steps_run; 1 if the blocks could not all become resident (nothing was modified) or 2 if a hop
+// timed out in mid-loop (outputs partial: the caller re-zeroes them) -- in both cases the caller falls back to the per-step
+// graph; or a negative TTS_HIP_E* code.  Synchronizes `st`.
 int persist_decode(tts_hip_engine* e, hipStream_t st, const PersistCall& c, int* steps_run);
 // load-time part: folded prenet-1 matrix etc. (called from tacotron2_finalize)
 int persist_finalize(tts_hip_engine* e, const HostTensor* prenet0, const HostTensor* proj_k, const HostTensor* proj_b,

@@ -54,7 +54,7 @@ constexpr int PRE = 256, RNN = 1024, ATT = 128, NMEL = 80, LOCK = 31;
 constexpr int PMW = 36;                   // floats per (row, position) of the LDS copy of PM: 16 att | 16 dec | F | proj | pad
 constexpr int PM_ATT = PERSIST_COL_ATT, PM_DEC = PERSIST_COL_DEC, PM_F = PERSIST_COL_F, PM_P = PERSIST_COL_P;
 constexpr long long SPIN_LIMIT = 1 << 19; // polls of one hop (~1 us each) before giving up
-constexpr long long RDV_LIMIT = 1 << 21;  // start-up rendezvous (s_sleep'd polls): other kernels may have to drain first
+constexpr long long RDV_LIMIT = 1 << 16;  // start-up rendezvous (s_sleep'd polls, ~0.1 s): other kernels may have to drain first
 constexpr int ABORT_RENDEZVOUS = 1, ABORT_TIMEOUT = 2;
 
 struct Xch {                              // offsets (in 8-byte entries) inside one parity half of the exchange area
@@ -951,7 +951,12 @@ int persist_decode(tts_hip_engine* e, hipStream_t st, const PersistCall& c, int*
     }
 #endif
     if (h[0] == ABORT_RENDEZVOUS) return 1;
-    if (h[0] != 0) return set_err(e, TTS_HIP_EHIP, "tacotron2 persistent decoder: exchange timed out at a hop (code %d)", h[0]);
+    if (h[0] != 0) {
+        // a hop timed out in mid-loop (never seen; e.g. a block lost its CU for a second): the outputs are partial -- the
+        // caller clears them and runs the per-step graph instead
+        set_err(e, TTS_HIP_EHIP, "tacotron2 persistent decoder: exchange timed out at a hop (code %d); fell back to the per-step graph", h[0]);
+        return 2;
+    }
     *steps_run = h[2];
     return TTS_HIP_OK;
 }

@@ -1366,10 +1366,15 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
     if (A.off > A.cap) return set_err(e, TTS_HIP_ENOMEM, "tacotron2 workspace accounting error");
     // all recurrent state, loop state, exchange area, histories and outputs of the real rows start at zero
     const size_t zero_from = (char*)d_state - A.base, zero_mid = (char*)d_decout - A.base;
-    HIPCHK(e, hipMemsetAsync(A.base + zero_from, 0, zero_mid - zero_from, st));
-    HIPCHK(e, hipMemsetAsync(d_decout, 0, (size_t)RD * NMEL * 4, st));
-    HIPCHK(e, hipMemsetAsync(d_stop, 0, (size_t)RD * 4, st));
-    HIPCHK(e, hipMemsetAsync(d_attn, 0, (size_t)RD * Tin * 4, st));
+    auto zero_state = [&]() -> int {
+        HIPCHK(e, hipMemsetAsync(A.base + zero_from, 0, zero_mid - zero_from, st));
+        HIPCHK(e, hipMemsetAsync(d_decout, 0, (size_t)RD * NMEL * 4, st));
+        HIPCHK(e, hipMemsetAsync(d_stop, 0, (size_t)RD * 4, st));
+        HIPCHK(e, hipMemsetAsync(d_attn, 0, (size_t)RD * Tin * 4, st));
+        return TTS_HIP_OK;
+    };
+    int rc;
+    if ((rc = zero_state())) return rc;
 
     // prenet dropout masks always travel through the workspace: a captured graph must not hold a caller's pointer
     const hipMemcpyKind kin = mem == TTS_HIP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
@@ -1458,7 +1463,6 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         timing_end(e);
         return TTS_HIP_OK;
     };
-    int rc;
     int host_steps = 0;
     bool persisted = false;
     int bl_err = 0;
@@ -1495,6 +1499,11 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         const int prc = persist_decode(e, st, pc, &host_steps);
         if (prc < 0) return prc;
         persisted = prc == TTS_HIP_OK;                  // 1: the grid could not become resident -> per-step graph below
+        if (prc == 2) {                                 // gave up in mid-loop: start over on the per-step graph
+            if ((rc = zero_state())) return rc;
+            hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
+            HIPCHK(e, hipGetLastError());
+        }
     }
     tc.last_path = persisted ? 1 : 0;
     if (!persisted) {
