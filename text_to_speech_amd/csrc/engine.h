@@ -132,6 +132,7 @@ struct Tacotron2Dev {
     float* pfold_b = nullptr;           // [256]
     int persist_mode = 1;               // 1: use the persistent decoder when the call shape allows it; 0: per-step graph only
     int last_path = -1;                 // how the last call ran its loop: 1 persistent kernel, 0 per-step graph
+    bool persist_timed = true;          // persistent kernel: timed optimistic polls on (switched off if they mostly miss)
     ConvBnDev post_conv[5];
     std::vector<void*> allocs;
     DevBuf ws;                          // per-call workspace arena
