@@ -129,8 +129,8 @@ def from_nvidia_waveglow(state_dict, cfg: WaveGlowConfig = WaveGlowConfig()):
 
 # ---- Keras checkpoints (the reference's own `.weights.h5` files) ------------------------------------------------------------
 # The reference stores its models as Keras 3 `ckpt-XXXX.weights.h5` (custom_train_objects/checkpoint_manager.py:148-215).
-# HDF5 cannot be read here (no h5py), and the H5 group names depend on the Keras version, so the supported route is a
-# two-step one:  (1) where the reference runs (Keras + h5py installed), `scripts/export_keras_weights.py <model name>`
+# Two routes.  The direct one (`from_keras_h5`, further down) reads the H5 file itself.  The name-based one, which lets
+# Keras itself resolve the file, has two steps:  (1) where the reference runs (Keras + h5py installed), `scripts/export_keras_weights.py <model name>`
 # restores the model with the reference's own code and writes `{variable.path: value}` to a `.safetensors` file;
 # (2) here, `from_keras_variables` maps those variable paths onto the engine's manifest.  Keras layouts ARE the manifest's
 # layouts (Dense [in, out], Conv1D [k, in, out], Conv1DTranspose [k, out, in], LSTM kernel / recurrent_kernel / bias with
@@ -211,6 +211,108 @@ def from_keras_variables(named, model: str, cfg=None):
         if target in out:
             raise ValueError(f'{origin[target]!r} and {path!r} both map to {target}')
         out[target], origin[target] = _np(value), path
+    return _checked(out, manifest)
+
+
+# ---- Keras `.weights.h5` read directly (pure-Python HDF5 reader; no Keras, no h5py) --------------------------------------------
+# Keras 3 `save_weights` does not store variable names: `saving_lib._save_state` walks the OBJECT TREE and writes each
+# layer's variables as `<path>/vars/<i>` (i = position in `trainable + non-trainable` order), where <path> is made of
+# attribute names (`decoder/cell/attention_rnn`) and, inside lists and Functional / Sequential models, of the snake-cased
+# class name with a per-container counter (`layers/conv1d`, `layers/conv1d_1`, `denses/dense_1`).  The tree below is read off
+# the reference's classes (architectures/tacotron2_arch.py:143-171 Prenet, :214-333 Postnet / Encoder (Functional models
+# built by simple_cnn), :336-362 DecoderCell, :492-509 Decoder, :752-795 Tacotron2; layers/location_sensitive_attention.py:
+# 27-75; waveglow_arch.py:27-90 WaveglowBlock, :159-225 WaveGlow; layers/invertible_conv.py:16-37).  One point depends on
+# the Keras release: whether the walk also descends through `Model.layers` (alphabetically between a subclassed model's own
+# attributes); where that could move a layer, BOTH paths are accepted and the file decides.  Every tensor is shape-checked
+# against the manifest.  Unverified against a real checkpoint of the reference (none is available here); the H5 parsing
+# itself is verified against libhdf5-written files and the tree against hand-written layouts (tests/test_keras_h5.py).
+_BN_VARS = ('gamma', 'beta', 'moving_mean', 'moving_variance')
+_LSTM_VARS = ('kernel', 'recurrent_kernel', 'bias')
+
+
+def _nth(name, k):
+    return name if k == 0 else f'{name}_{k}'
+
+
+def keras_h5_layout(model: str, cfg=None):
+    """[(manifest prefix, variable names in `vars/<i>` order, candidate H5 scopes)] for `model`."""
+    out = []
+    if model == 'tacotron2':
+        cfg = cfg or Tacotron2Config()
+        convs = ('conv1d', 'masked_conv1d')
+        out.append(('tacotron2/encoder', ('embeddings',), ['encoder/layers/custom_embedding']))
+        for section, n, roots in (('encoder', cfg.encoder_n_conv, ['encoder/layers']),
+                                  ('postnet', cfg.postnet_n_conv, ['postnet/layers', 'layers/functional_1/layers'])):
+            for i in range(n):
+                out.append((f'tacotron2/{section}/conv_{i + 1}', ('kernel', 'bias'),
+                            [f'{r}/{_nth(c, i)}' for r in roots for c in convs]))
+                out.append((f'tacotron2/{section}/norm_{i + 1}', _BN_VARS,
+                            [f'{r}/{_nth("batch_normalization", i)}' for r in roots]))
+        for d in ('forward', 'backward'):
+            out.append((f'tacotron2/encoder/bi_lstm/{d}', _LSTM_VARS, [f'encoder/layers/bidirectional/{d}_layer/cell']))
+        for i in range(len(cfg.prenet_sizes)):
+            out.append((f'tacotron2/decoder/prenet/layer_{i}', ('kernel',),
+                        [f'{r}/denses/{_nth("dense", i)}' for r in ('decoder/prenet', 'decoder/layers/tacotron2_prenet')]))
+        cell = 'decoder/cell'
+        out.append(('tacotron2/decoder/attention_rnn', _LSTM_VARS, [f'{cell}/attention_rnn']))
+        for name in ('query_layer', 'memory_layer', 'value_layer'):
+            out.append((f'tacotron2/decoder/lsa/{name}', ('kernel',), [f'{cell}/attention_layer/{name}']))
+        out.append(('tacotron2/decoder/lsa/location_conv', ('kernel',), [f'{cell}/attention_layer/location_layer/layers/conv1d']))
+        out.append(('tacotron2/decoder/lsa/location_dense', ('kernel',), [f'{cell}/attention_layer/location_layer/layers/dense']))
+        out.append(('tacotron2/decoder/decoder_rnn/cell_0', _LSTM_VARS, [f'{cell}/decoder_rnn/cells/lstm_cell']))
+        out.append(('tacotron2/decoder/linear_projection', ('kernel', 'bias'), ['decoder/linear_projection', 'decoder/layers/dense']))
+        out.append(('tacotron2/decoder/gate_output', ('kernel', 'bias'), ['decoder/gate_layer']))
+    elif model == 'waveglow':
+        cfg = cfg or WaveGlowConfig()
+        out.append(('waveglow/upsample', ('kernel', 'bias'), ['upsample', 'layers/conv1d_transpose']))
+        for k in range(cfg.n_flows):
+            out.append((f'waveglow/invertible_conv-{k}/conv', ('kernel',), [f'convinv/{_nth("invertible1x1_conv", k)}/conv']))
+            blk = f'blocks/{_nth("waveglow_block", k)}'
+            # order of WaveglowBlock.layers (waveglow_arch.py:58-90): start, end, then in / cond / res_skip per layer
+            out.append((f'waveglow/block-{k}/start_conv', ('kernel', 'bias'), [f'{blk}/start', f'{blk}/layers/conv1d']))
+            out.append((f'waveglow/block-{k}/end_conv', ('kernel', 'bias'), [f'{blk}/end']))
+            for i in range(cfg.n_layers):
+                out.append((f'waveglow/block-{k}/in_conv-{i}', ('kernel', 'bias'), [f'{blk}/in_layers/{_nth("conv1d", i)}']))
+                out.append((f'waveglow/block-{k}/cond_layer-{i}', ('kernel', 'bias'), [f'{blk}/cond_layers/{_nth("conv1d", i)}']))
+                out.append((f'waveglow/block-{k}/res_skip_conv-{i}', ('kernel', 'bias'),
+                            [f'{blk}/res_skip_layers/{_nth("conv1d", i)}', f'{blk}/layers/{_nth("conv1d", 4 + 3 * i)}']))
+    else:
+        raise ValueError(f"model must be 'tacotron2' or 'waveglow', got {model!r}")
+    return out
+
+
+def from_keras_h5(path, model: str, cfg=None):
+    """A Keras 3 `.weights.h5` file of the reference's Tacotron2 / WaveGlow -> manifest tensors (see the note above)."""
+    from .hdf5_reader import H5File
+    if model == 'tacotron2':
+        manifest = tacotron2_manifest(cfg or Tacotron2Config())
+    elif model == 'waveglow':
+        manifest = waveglow_manifest(cfg or WaveGlowConfig())
+    else:
+        raise ValueError(f"model must be 'tacotron2' or 'waveglow', got {model!r}")
+    with H5File(path) as f:
+        scopes = {}
+        for p, ds in f.datasets().items():
+            parts = p.strip('/').split('/')
+            if len(parts) >= 2 and parts[-2] == 'vars' and parts[-1].isdigit():
+                scopes.setdefault('/'.join(parts[:-2]), {})[int(parts[-1])] = ds
+        out = {}
+        for prefix, names, candidates in keras_h5_layout(model, cfg):
+            wanted = [n for n in names if f'{prefix}/{n}' in manifest]
+            if not wanted:
+                continue
+            present = [c for c in candidates if c in scopes]
+            if len(present) != 1:
+                near = sorted(s for s in scopes if s.split('/')[0] == candidates[0].split('/')[0])[:12]
+                raise KeyError(f'{prefix}: expected exactly one of the H5 groups {candidates} (+ /vars), found {present}; '
+                               f'groups of the file under the same root: {near}')
+            found = scopes[present[0]]
+            if sorted(found) != list(range(len(names))) and sorted(found) != list(range(len(wanted))):
+                raise ValueError(f'{prefix}: H5 group {present[0]}/vars holds variables {sorted(found)}, expected {len(names)} ({names})')
+            order = names if len(found) == len(names) else wanted
+            for i, n in enumerate(order):
+                if f'{prefix}/{n}' in manifest:
+                    out[f'{prefix}/{n}'] = found[i].read()
     return _checked(out, manifest)
 
 
@@ -322,6 +424,8 @@ def main(argv=None):
     ap.add_argument('--waveglow', help='NVIDIA WaveGlow checkpoint (.pt, weight norm allowed)')
     ap.add_argument('--keras-tacotron2', help='Keras variables of the Tacotron2 model (scripts/export_keras_weights.py output)')
     ap.add_argument('--keras-waveglow', help='Keras variables of the WaveGlow model (scripts/export_keras_weights.py output)')
+    ap.add_argument('--keras-h5-tacotron2', help="the reference's Tacotron2 `.weights.h5` checkpoint, read directly")
+    ap.add_argument('--keras-h5-waveglow', help="the reference's WaveGlow `.weights.h5` checkpoint, read directly")
     ap.add_argument('--speaker-embedding-dim', type=int, default=0, help='256 for the SV2TTS Tacotron2')
     ap.add_argument('-o', '--output', required=True, help='TTSW file to write')
     args = ap.parse_args(argv)
@@ -333,6 +437,11 @@ def main(argv=None):
                                                 Tacotron2Config(speaker_embedding_dim=args.speaker_embedding_dim)))
         if args.keras_waveglow:
             tensors.update(from_keras_variables(load_file(args.keras_waveglow), 'waveglow'))
+    if args.keras_h5_tacotron2:
+        tensors.update(from_keras_h5(args.keras_h5_tacotron2, 'tacotron2',
+                                     Tacotron2Config(speaker_embedding_dim=args.speaker_embedding_dim)))
+    if args.keras_h5_waveglow:
+        tensors.update(from_keras_h5(args.keras_h5_waveglow, 'waveglow'))
     if args.tacotron2 or args.waveglow:
         import torch
     if args.tacotron2:
