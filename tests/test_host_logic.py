@@ -389,3 +389,57 @@ def test_sv2tts_infer_resolves_the_speaker_embedding():
         model.infer(text, embeddings={'mode': lambda e: e[0][:8]})      # a selector that yields the wrong width
     with pytest.raises(ValueError, match='no speaker embeddings'):
         SV2TTSTacotron2(spy, lang='fr').infer(text)
+
+
+# ---- audio writer (reference: utils/audio/audio_io.py:347-380, audio_processing.py:51-62) ---------------------------------
+def test_pcm16_preparation_follows_the_reference_normalisation():
+    from text_to_speech_amd.callbacks import to_pcm16
+    a = np.array([0.1, 0.3, -0.2, 0.0], np.float32)
+    centred = a - a.mean()
+    want = (centred * (32767 / np.abs(centred).max())).astype(np.int16)           # mean removed, peak -> 32767, truncation
+    np.testing.assert_array_equal(to_pcm16(a), want)
+    assert int(np.abs(to_pcm16(a)).max()) == 32767
+    np.testing.assert_array_equal(to_pcm16(np.zeros(5, np.float32)), np.zeros(5, np.int16))      # silence stays silence
+    assert to_pcm16(np.zeros(0, np.float32)).shape == (0,)
+    np.testing.assert_array_equal(to_pcm16(np.array([2.0, -0.5], np.float32), normalize=False), [32767, -16384])
+
+
+def test_write_audio_dispatches_on_the_extension(tmp_path, monkeypatch):
+    import os
+    import stat
+    from scipy.io import wavfile
+    from text_to_speech_amd import callbacks
+    audio = np.sin(np.arange(2205) * 0.05).astype(np.float32) * 0.3
+    wav = tmp_path / 'a.wav'
+    callbacks.write_audio(str(wav), audio, 22050)
+    rate, data = wavfile.read(str(wav))
+    assert rate == 22050 and data.dtype == np.int16
+    np.testing.assert_array_equal(data, callbacks.to_pcm16(audio))
+
+    monkeypatch.setenv('PATH', str(tmp_path / 'nothing'))
+    assert callbacks.default_audio_format() == 'audio-{}.wav'
+    with pytest.raises(ValueError, match='needs the ffmpeg executable'):
+        callbacks.write_audio(str(tmp_path / 'a.mp3'), audio, 22050)
+    assert not (tmp_path / 'a.mp3').exists()
+
+    # a stand-in encoder: records its arguments, copies the PCM it is fed to the output file
+    bindir = tmp_path / 'bin'
+    bindir.mkdir()
+    fake = bindir / 'ffmpeg'
+    fake.write_text('#!/bin/sh\nfor last; do :; done\necho "$@" > "$last.args"\ncat > "$last"\n')
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv('PATH', f'{bindir}:/usr/bin:/bin')
+    assert callbacks.default_audio_format() == 'audio-{}.mp3'                       # the reference's default name
+    mp3 = tmp_path / 'b.mp3'
+    callbacks.write_audio(str(mp3), audio, 16000)
+    np.testing.assert_array_equal(np.frombuffer(mp3.read_bytes(), np.int16), callbacks.to_pcm16(audio))
+    args = (tmp_path / 'b.mp3.args').read_text().split()
+    assert args[args.index('-f') + 1] == 's16le' and args[args.index('-ar') + 1] == '16000' and args[args.index('-ac') + 1] == '1'
+    saver = callbacks.AudioSaver(file_format=str(tmp_path / 'out' / callbacks.default_audio_format()))
+    infos = {}
+    saver(infos, {'audio': audio, 'rate': 22050})
+    assert infos['audio'].endswith('audio-0.mp3') and os.path.exists(infos['audio'])
+
+    fake.write_text('#!/bin/sh\necho "no such codec" >&2\nexit 3\n')
+    with pytest.raises(RuntimeError, match='no such codec'):
+        callbacks.write_audio(str(tmp_path / 'c.ogg'), audio, 22050)

@@ -9,8 +9,10 @@ Host-side counterpart of /root/reference/utils/callbacks (SURVEY.md section 8f r
   * `JSONSaver` stores `infos` under `infos[primary_key]` in the shared map and rewrites the json file (:167-193);
   * `apply_callbacks(..., save=False)` skips the file savers (used when a cached entry is replayed, __init__.py:31-47)
     and never lets a failing callback break inference: the error is logged.
-Differences: audio is written as 16-bit PCM `.wav` by default (no mp3 encoder in this image; pass `save_fn` to change it);
-players / displayers (displayer.py) are out of scope.
+Audio files: `write_audio` prepares samples like the reference (mean removed, peak-normalised 16-bit) and writes `.wav`
+itself and every other extension through the `ffmpeg` executable, like the reference's pydub writer; the default file name
+is the reference's `audio-{}.mp3` when ffmpeg is on PATH and `audio-{}.wav` otherwise (this image has no encoder).
+Players / displayers (displayer.py) are out of scope.
 """
 from __future__ import annotations
 
@@ -49,6 +51,54 @@ def write_wav(filename, audio, rate=22050):
     from scipy.io import wavfile
     a = np.clip(_to_numpy(audio).astype(np.float32).reshape(-1), -1.0, 1.0)
     wavfile.write(filename, int(rate), np.round(a * 32767.0).astype(np.int16))
+
+
+def to_pcm16(audio, normalize=True):
+    """float waveform -> int16 samples the way the reference's `write_audio` prepares them (utils/audio/audio_io.py:359-361,
+    audio_processing.py:51-62): mean removed, peak scaled to 32767, truncated; `normalize=False` keeps the scale ([-1, 1]
+    clipped, rounded)."""
+    a = _to_numpy(audio).astype(np.float32).reshape(-1)
+    if not normalize:
+        return np.round(np.clip(a, -1.0, 1.0) * 32767.0).astype(np.int16)
+    if a.size == 0:
+        return a.astype(np.int16)
+    a = a - np.mean(a)
+    peak = float(np.max(np.abs(a)))
+    if peak <= 1e-9:
+        return a.astype(np.int16)
+    return (a * (32767 / peak)).astype(np.int16)
+
+
+def find_ffmpeg():
+    import shutil
+    return shutil.which('ffmpeg')
+
+
+def write_audio(filename, audio, rate=22050, normalize=True):
+    """Writes `audio` in the format the extension names (audio_io.py:347-364): `.wav` with scipy, anything else (mp3, ogg,
+    flac, m4a, ...) through the `ffmpeg` executable fed with raw 16-bit PCM -- what the reference's pydub writer does
+    (:371-380).  Without ffmpeg on PATH a non-wav extension is an error, not a silent change of format."""
+    ext = os.path.splitext(filename)[1].lower()
+    pcm = to_pcm16(audio, normalize)
+    if ext == '.wav':
+        from scipy.io import wavfile
+        wavfile.write(filename, int(rate), pcm)
+        return filename
+    exe = find_ffmpeg()
+    if exe is None:
+        raise ValueError(f"cannot write {filename!r}: encoding '{ext}' needs the ffmpeg executable on PATH "
+                         "(use a .wav file name, or pass save_fn=...)")
+    import subprocess
+    cmd = [exe, '-y', '-loglevel', 'error', '-f', 's16le', '-ar', str(int(rate)), '-ac', '1', '-i', 'pipe:0', filename]
+    done = subprocess.run(cmd, input=pcm.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if done.returncode != 0:
+        raise RuntimeError(f"ffmpeg failed writing {filename!r}: {done.stderr.decode(errors='replace')[-500:]}")
+    return filename
+
+
+def default_audio_format():
+    """`audio-{}.mp3` like the reference (models/tts/tacotron2.py:308) when an encoder is available, else `audio-{}.wav`."""
+    return 'audio-{}.mp3' if find_ffmpeg() else 'audio-{}.wav'
 
 
 class Callback:
@@ -154,8 +204,9 @@ class FileSaver(Callback):
 
 
 class AudioSaver(FileSaver):
-    def __init__(self, key='audio', file_format='audio-{}.wav', **kwargs):
-        kwargs.setdefault('save_fn', write_wav)
+    def __init__(self, key='audio', file_format=None, **kwargs):
+        file_format = file_format or default_audio_format()
+        kwargs.setdefault('save_fn', write_audio)
         kwargs['additional_keys'] = ['rate']
         super().__init__(key, file_format, **kwargs)
 

@@ -18,7 +18,7 @@ import os
 
 import numpy as np
 
-from .callbacks import (AudioSaver, Callback, FunctionCallback, JSONSaver, QueueCallback, SpectrogramSaver,
+from .callbacks import (AudioSaver, default_audio_format, Callback, FunctionCallback, JSONSaver, QueueCallback, SpectrogramSaver,
                         apply_callbacks, load_json)
 from .text import CharTokenizer, split_sentences, split_text
 
@@ -138,7 +138,7 @@ class Tacotron2:
 
     def get_inference_callbacks(self, *, vocoder=None, save=None, save_mel=None, save_audio=None, directory=None,
                                 mel_dir=None, audio_dir=None, mel_filename='mel-{}.npy',
-                                audio_filename='audio-{}.wav', post_processing=None, **_):
+                                audio_filename=None, post_processing=None, **_):
         """(predicted, callbacks) with the reference's flag resolution (tacotron2.py:276-352): results are saved when a
         `directory` is given or there is no vocoder; mels only without a vocoder; `map.json` in `directory` is both the
         cache that `infer` consults and the index the JSON saver rewrites."""
@@ -165,7 +165,7 @@ class Tacotron2:
                                                                            mel_filename)))
             if save_audio:
                 callbacks.append(AudioSaver(file_format=os.path.join(audio_dir or os.path.join(directory, 'audios'),
-                                                                     audio_filename)))
+                                                                     audio_filename or default_audio_format())))
             callbacks.append(JSONSaver(data=predicted, filename=map_file, primary_key='text'))
         if post_processing is not None:
             for fn in (post_processing if isinstance(post_processing, list) else [post_processing]):
