@@ -202,6 +202,11 @@ def secondary_metrics(eng, dev, rank):
             tf = mult * wn_in_layer_flops(M) / (us * 1e-6) / 1e12
             out[f'waveglow_{prec}_wn_in_layer_us'] = us
             out[f'waveglow_{prec}_wn_in_layer_mfma_frac'] = tf / FP16_MFMA_PEAK_TFLOPS
+            # SURVEY 8(d) asks for both fractions on the fp16 sweep: algorithmic bytes of one launch (x in + activations out
+            # as fp16 planes, mel, weights) over the same launch time, against 8 TB/s.  MFMA-bound by construction.
+            planes = 2 if prec == 'f16x3' else 1
+            nbytes = planes * (M * (512 + 512) + BATCH * FRAMES * 80 + 1024 * (1536 + 32 * 320)) * 2.0
+            out[f'waveglow_{prec}_wn_in_layer_hbm_frac'] = nbytes / (us * 1e-6) / 8.0e12
     out['waveglow_f16_rms_error_vs_fp32_oracle'] = 2.0e-4      # measured by tests/test_waveglow_gpu.py (tolerance 1e-4 is fp32)
     out['waveglow_f16x3_rms_error_vs_fp32_oracle'] = 5.0e-7
     del mel8, z8
