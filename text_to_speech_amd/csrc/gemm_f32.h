@@ -30,6 +30,11 @@
 #ifndef TTS_ABL
 #define TTS_ABL 0
 #endif
+// fp16 kernels issue v_mfma_f32_16x16x32_f16 (1) or v_mfma_f32_32x32x16_f16 (0): equal cycles per FLOP, but under load the
+// chip holds a higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS item 7; measured here: DESIGN.md 4.1b).
+#ifndef TTS_H16
+#define TTS_H16 1
+#endif
 
 namespace ttsgemm {
 
@@ -190,24 +195,47 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 
     const int lrow = tid / TPR;         // row inside a staging pass
     // k offset of this thread's float4.  DMA: LDS slot (row, c') receives global chunk c' ^ ((row >> 2) & 3)
-    const int c4 = DMA ? (((tid & 3) ^ ((tid >> 4) & 3)) * 4) : (tid % TPR) * 4;
+    //          (H16: c' ^ (-(row >> 2) & 3), the permutation that makes the 16-row x 4-chunk operand reads conflict-free)
+    const int c4 = DMA ? (((tid & 3) ^ ((TTS_H16 && HALF ? -(tid >> 4) : (tid >> 4)) & 3)) * 4) : (tid % TPR) * 4;
     const int li = lane & 31, lh = lane >> 5;
+    // Accumulator register r of a 32 x 32 tile holds (row trow(r), column tcol(r)) of the tile.  32x32 MFMA: column =
+    // lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  H16 (four 16x16x32 sub-tiles, registers 4 s .. 4 s + 3 for
+    // s = 2 ri + cj): row = 16 ri + 4 (lane >> 4) + (r & 3), column = 16 cj + (lane & 15).
+    constexpr bool H16 = HALF && TTS_H16;
+    auto trow = [&](int r) -> int { return H16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * lh; };
+    auto tcol = [&](int r) -> int { return H16 ? 16 * ((r >> 2) & 1) + (lane & 15) : li; };
 
     // ---- accumulators start from bias (+ the previous output value for read-modify-write epilogues), so the
     //      epilogue is a pure store and the old values are fetched under the first tile's load latency
     const float* bias = g.bias ? g.bias + z * g.strideBiasZ : nullptr;
-    const int rbase = m0 + wr * RT * 32 + 4 * lh;
-    const int cbase = n0 + wc * CT * 32 + li;
+    const int rbase = m0 + wr * RT * 32;             // + trow(r): first row of the wave's tiles
+    const int cbase = n0 + wc * CT * 32;             // + tcol(r): first column of the wave's tiles
     // the output side (out0 / out1) is uniform per block: `split` is a multiple of BN or >= N (checked at launch)
     const bool second = n0 >= g.split;
     float* const outp = (second ? g.out1 : g.out0) + z * g.strideOutZ;
     const long long ldo = second ? g.ld1 : g.ld0;
-    const int ncol0 = second ? cbase - g.split : cbase;     // this lane's first output column on that side
-    f32x16 acc[RT][CT];
+    const int ncol0 = second ? cbase - g.split : cbase;     // the wave's first output column on that side
+    // 32 x 32 accumulator tiles: one f32x16 per tile (32x32 MFMA), or four f32x4 sub-tiles (H16) -- separate values, so that
+    // the compiler never has to carry a 16-register tuple through control flow for a 4-register update
+    f32x16 acc[H16 ? 1 : RT][H16 ? 1 : CT];
+    f32x4 accq[H16 ? RT : 1][H16 ? CT : 1][4];
+    auto A = [&](int i, int j, int r) -> float {
+        if constexpr (H16) return accq[i][j][r >> 2][r & 3];
+        else return acc[i][j][r];
+    };
+    auto setA = [&](int i, int j, int r, float v) {
+        if constexpr (H16) accq[i][j][r >> 2][r & 3] = v;
+        else acc[i][j][r] = v;
+    };
     {
-        float bv[CT];
+        float bv[CT][2];                             // per column half (the 32x32 layout has one column per lane)
 #pragma unroll
-        for (int j = 0; j < CT; ++j) bv[j] = (bias && cbase + j * 32 < g.N) ? bias[cbase + j * 32] : 0.f;
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = cbase + j * 32 + tcol(4 * h);
+                bv[j][h] = (bias && n < g.N) ? bias[n] : 0.f;
+            }
         const bool rmw = g.mode == EPI_LINEAR && (second ? g.acc1 : g.acc0) && !(DMA && g.wide_epi);
         if (rmw) {
             // branch-free batch of dword buffer loads (rows >= M and columns >= N read as 0), one wait for all
@@ -218,10 +246,10 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int rl = 4 * lh + i * 32 + (r & 3) + 8 * (r >> 2);      // row inside the wave's rows
-                        const bool ok = (m0 + wr * RT * 32 + rl < g.M) && (cbase + j * 32 < g.N);
-                        const unsigned off = ok ? (unsigned)((rl * (int)ldo + ncol0 + j * 32) * 4) : OOB;
-                        acc[i][j][r] = bv[j] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, off, 0, 0));
+                        const int rl = i * 32 + trow(r);                               // row inside the wave's rows
+                        const bool ok = (rbase + rl < g.M) && (cbase + j * 32 + tcol(r) < g.N);
+                        const unsigned off = ok ? (unsigned)((rl * (int)ldo + ncol0 + j * 32 + tcol(r)) * 4) : OOB;
+                        setA(i, j, r, bv[j][(r >> 2) & 1] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, off, 0, 0)));
                     }
         } else {
 #pragma unroll
@@ -229,7 +257,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 #pragma unroll
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
+                    for (int r = 0; r < 16; ++r) setA(i, j, r, bv[j][(r >> 2) & 1]);
         }
     }
 
@@ -386,8 +414,61 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     };
 
     // ---- MFMA on one LDS buffer
+    auto mfma_h = [](f16x8 x, f16x8 y, f32x16 c) -> f32x16 { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); };
+    // 16x16x32: sub-tile s = 2 * ri + cj of a 32 x 32 accumulator tile
+    auto mfma_q = [](f16x8 x, f16x8 y, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0); };
     const int xr = (li >> 2) & 3;                    // DMA image: chunk XOR of this lane's operand rows
     auto compute_chunk = [&](int buf, int k8) {
+        if constexpr (H16) {
+            // one call covers the whole 64-byte stage (K = 32 halfs): lane (row q = lane & 15, chunk c = lane >> 4) of a
+            // 16-row operand block reads logical chunk c of its row, stored at slot c ^ (-(q >> 2) & 3)
+            if (k8 != 0) return;
+            const int q16 = lane & 15;
+            const int ko = (((lane >> 4) ^ (-(q16 >> 2))) & 3) * 4;
+            const float* a = As + buf * PL * BM * LDSK + (wr * RT * 32 + q16) * LDSK + ko;
+            const float* b = Bs + buf * PL * BN * LDSK + (wc * CT * 32 + q16) * LDSK + ko;
+            f32x4 fa[RT][2], fb[CT][2];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) fa[i][h] = *reinterpret_cast<const f32x4*>(a + (i * 32 + h * 16) * LDSK);
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) fb[j][h] = *reinterpret_cast<const f32x4*>(b + (j * 32 + h * 16) * LDSK);
+            if constexpr (PL == 2) {
+                f32x4 fal[RT][2], fbl[CT][2];
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) fal[i][h] = *reinterpret_cast<const f32x4*>(a + (BM + i * 32 + h * 16) * LDSK);
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) fbl[j][h] = *reinterpret_cast<const f32x4*>(b + (BN + j * 32 + h * 16) * LDSK);
+                // hi*lo and lo*hi first, hi*hi last: the small terms are added before the large one lands in the fp32 sum
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx) {
+                            const int ri = sidx >> 1, cj = sidx & 1;
+                            mfma_q(__builtin_bit_cast(f16x8, fal[i][ri]), __builtin_bit_cast(f16x8, fb[j][cj]), accq[i][j][sidx]);
+                            mfma_q(__builtin_bit_cast(f16x8, fa[i][ri]), __builtin_bit_cast(f16x8, fbl[j][cj]), accq[i][j][sidx]);
+                            mfma_q(__builtin_bit_cast(f16x8, fa[i][ri]), __builtin_bit_cast(f16x8, fb[j][cj]), accq[i][j][sidx]);
+                        }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        mfma_q(__builtin_bit_cast(f16x8, fa[i][sidx >> 1]), __builtin_bit_cast(f16x8, fb[j][sidx & 1]), accq[i][j][sidx]);
+            return;
+        }
         const int koff = DMA ? (((2 * k8 + lh) ^ xr) * 4) : (lh * 4 + k8 * 8);
         const float* a = As + buf * PL * BM * LDSK + (wr * RT * 32 + li) * LDSK + koff;
         const float* b = Bs + buf * PL * BN * LDSK + (wc * CT * 32 + li) * LDSK + koff;
@@ -408,12 +489,9 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < CT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fal[i]),
-                                                                       __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]),
-                                                                       __builtin_bit_cast(f16x8, fbl[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]),
-                                                                       __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_h(__builtin_bit_cast(f16x8, fal[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j]);
+                    acc[i][j] = mfma_h(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fbl[j]), acc[i][j]);
+                    acc[i][j] = mfma_h(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j]);
                 }
             return;
         }
@@ -433,8 +511,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]),
-                                                                       __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_h(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j]);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -535,7 +612,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     }
 
     // ---------------- epilogue ----------------
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // C/D map of a 32 x 32 tile: trow(r) / tcol(r) (defined with the accumulators above)
     if constexpr (CT % 2 == 0) {
         if (g.mode == EPI_GATE) {
             // weight rows are permuted at load time in groups of 64: 32 tanh pre-activations followed by the 32 matching
@@ -557,8 +634,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                             const int mrow0 = m0 + wr * RT * 32 + i * 32;
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
-                                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] =
-                                    gate_tanh_sigmoid(acc[i][2 * q][r], acc[i][2 * q + 1][r]);
+                                patch[trow(r) * 36 + tcol(r)] = gate_tanh_sigmoid(A(i, 2 * q, r), A(i, 2 * q + 1, r));
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                             for (int qq = 0; qq < 4; ++qq) {
@@ -586,12 +662,12 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int q = 0; q < CT / 2; ++q) {
-                    const int ch = ((n0 + wc * CT * 32) / 64 + q) * 32 + li;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                        const int ch = ((n0 + wc * CT * 32) / 64 + q) * 32 + tcol(r);
+                        const int m = rbase + i * 32 + trow(r);
                         if (m < g.M) {
-                            const float gv = gate_tanh_sigmoid(acc[i][2 * q][r], acc[i][2 * q + 1][r]);
+                            const float gv = gate_tanh_sigmoid(A(i, 2 * q, r), A(i, 2 * q + 1, r));
                             if constexpr (HALF) {
                                 const _Float16 hv = (_Float16)gv;
                                 g.out0h[(long long)m * g.ld0h + ch] = hv;
@@ -621,7 +697,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 #pragma unroll
                 for (int j = 0; j < CT; ++j) {
                     const int mrow0 = m0 + wr * RT * 32 + i * 32;
-                    const int ncol = ncol0 - li + j * 32 + pc4;  // first of this lane's 4 output columns
+                    const int ncol = ncol0 + j * 32 + pc4;       // first of this lane's 4 output columns
                     f32x4 oldv[4];
                     if (accum) {
 #pragma unroll
@@ -629,7 +705,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                             oldv[q] = *reinterpret_cast<const f32x4*>(outp + (long long)(mrow0 + prow + 8 * q) * ldo + ncol);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) patch[trow(r) * 36 + tcol(r)] = A(i, j, r);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private patch: no barrier needed
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -661,15 +737,15 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
-            const int n = cbase + j * 32;
-            if (n >= g.N) continue;
-            const int nc = ncol0 + j * 32;
-            const float ab = g.altbias ? g.altbias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                const int n = cbase + j * 32 + tcol(r);
+                if (n >= g.N) continue;
+                const int nc = ncol0 + j * 32 + tcol(r);
+                const float ab = g.altbias ? g.altbias[n] : 0.f;
+                const int m = rbase + i * 32 + trow(r);
                 if (m < g.M) {
-                    float v = acc[i][j][r];
+                    float v = A(i, j, r);
                     if (g.rowmask) {
                         const bool on = g.rowmask[m] != 0;
                         v = on ? v : (g.mask_out ? 0.f : ab);
