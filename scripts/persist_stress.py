@@ -32,8 +32,9 @@ def hammer():
 
 
 worst, ran = 0.0, {'persistent': 0, 'graph': 0}
+free0 = torch.cuda.mem_get_info()[0]
 t_start = time.time()
-for phase, contended in (('alone', False), ('contended', True)):
+for phase, contended in (('alone', False), ('contended', True), ('contended again', True), ('alone again', False)):
     th = None
     if contended:
         stop.clear()
@@ -74,4 +75,6 @@ for phase, contended in (('alone', False), ('contended', True)):
     if th is not None:
         stop.set()
         th.join()
-print(f'done: worst diff {worst:.2e}; persistent requests served by {ran}')
+    print(f'{phase}: device memory in use +{(free0 - torch.cuda.mem_get_info()[0]) / 2**20:.0f} MiB since start', flush=True)
+print(f'done: worst diff {worst:.2e}; persistent requests served by {ran}; device memory in use grew by '
+      f'{(free0 - torch.cuda.mem_get_info()[0]) / 2**20:.0f} MiB over the run (workspaces are high-water-mark arenas, graphs an LRU of 16)')
