@@ -178,7 +178,14 @@ def main():
         put(f, m, '/layouts/resizable', (5, 3), '<f4', maxshape=(None, 3))
         f.create_dataset('/layouts/unwritten', shape=(4, 2), dtype='<f4')    # allocated late: never written -> zeros
         m['/layouts/unwritten'] = [[4, 2], '<f4', 'zeros']
-        f['/types/string'] = 'not numeric'                                   # skipped by datasets()
+        f['/types/string'] = 'not numeric'                                   # scalar variable-length string
+        m['/types/string'] = [[], 'str', ['not numeric']]
+        words = ['alpha', '', 'bêta', 'gamma delta', 'e' * 300]              # empty, non-ASCII and long entries
+        f.create_dataset('/types/vlen_strings', data=np.array(words, dtype=object), dtype=h5py.string_dtype())
+        m['/types/vlen_strings'] = [[5], 'str', words]
+        f.create_dataset('/types/fixed_strings', data=np.array([b'ab', b'', b'wxyz'], dtype='S4'))
+        m['/types/fixed_strings'] = [[3], 'str', ['ab', '', 'wxyz']]
+        f.create_dataset('/types/compound', data=np.zeros(2, dtype=[('a', '<f4'), ('b', '<i4')]))   # skipped by datasets()
         f['/soft'] = h5py.SoftLink('/types/f64')                             # not followed
 
     # 3. libver='latest': superblock 3, version-2 object headers, link messages, layout version 4
@@ -195,6 +202,18 @@ def main():
     with h5py.File(os.path.join(HERE, 'latest_dense.h5'), 'w', libver='latest') as f:
         for i in range(12):
             f.create_dataset(f'/many/d{i}', data=np.zeros(2, np.float32))
+
+    # 4b. a speaker-embedding file the way the reference writes one (utils/file_utils.py:358-397 dump_h5 of a DataFrame:
+    #     one dataset per column, strings as variable-length strings, ragged vectors padded with -1)
+    m = manifest['embeddings_ref_format.h5'] = {}
+    with h5py.File(os.path.join(HERE, 'embeddings_ref_format.h5'), 'w') as f:
+        ids = ['siwis', 'siwis', 'bob', 'alice', 'bob']
+        files = [f'wavs/{i}_{k}.wav' for k, i in enumerate(ids)]
+        put(f, m, '/embedding', (5, 16))
+        f.create_dataset('/id', data=np.array(ids, dtype=object), dtype=h5py.string_dtype())
+        f.create_dataset('/filename', data=np.array(files, dtype=object), dtype=h5py.string_dtype())
+        m['/id'] = [[5], 'str', ids]
+        m['/filename'] = [[5], 'str', files]
 
     # 5. a user block in front of the superblock (superblock at offset 512)
     m = manifest['userblock.h5'] = {}

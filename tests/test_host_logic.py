@@ -443,3 +443,62 @@ def test_write_audio_dispatches_on_the_extension(tmp_path, monkeypatch):
     fake.write_text('#!/bin/sh\necho "no such codec" >&2\nexit 3\n')
     with pytest.raises(RuntimeError, match='no such codec'):
         callbacks.write_audio(str(tmp_path / 'c.ogg'), audio, 22050)
+
+
+# ---- speaker-embedding files (reference: utils/embeddings.py:30-212, utils/file_utils.py:252-292,358-397) ----------------------
+def test_embeddings_to_np_parses_the_reference_string_forms():
+    from text_to_speech_amd.embeddings import embeddings_to_np
+    np.testing.assert_allclose(embeddings_to_np('[0.5, -1.25, 3]'), [0.5, -1.25, 3.0])
+    np.testing.assert_allclose(embeddings_to_np('[0.5\t-1.25\t3]'), [0.5, -1.25, 3.0])
+    np.testing.assert_allclose(embeddings_to_np('[ 1.  2.5\n  3. ]'), [1.0, 2.5, 3.0])            # numpy's own repr
+    np.testing.assert_allclose(embeddings_to_np('[[1, 2] [3, 4]]'), [[1, 2], [3, 4]])
+    np.testing.assert_allclose(embeddings_to_np('[[1, 2, 3], [4, 5]]'), [[1, 2, 3], [4, 5, 0]])  # ragged rows are padded
+    m = np.arange(6, dtype=np.float32).reshape(2, 3)
+    assert embeddings_to_np(m) is m
+    np.testing.assert_allclose(embeddings_to_np({'embedding': ['[1, 2]', '[3, 4]']}), [[1, 2], [3, 4]])
+    with pytest.raises(ValueError, match='does not exist'):
+        embeddings_to_np('no/such/file.npy')
+
+
+def test_load_embeddings_reads_the_reference_h5_table_without_h5py():
+    import os
+    from test_hdf5_reader import H5, expected
+    from text_to_speech_amd.embeddings import load_embeddings
+    from text_to_speech_amd.tacotron2 import select_embedding
+    table = load_embeddings(os.path.join(H5, 'embeddings_ref_format'))          # extension resolved like the reference does
+    assert list(table['id']) == ['siwis', 'siwis', 'bob', 'alice', 'bob']
+    assert table['filename'][3] == 'wavs/alice_3.wav'
+    want = expected('/embedding', (5, 16), '<f4')
+    np.testing.assert_array_equal(np.stack(table['embedding'].values), want)
+    # aggregate_on = 'id', mode 0: every row gets the first embedding of its speaker
+    np.testing.assert_array_equal(table['speaker_embedding'][4], want[2])
+    np.testing.assert_array_equal(table['speaker_embedding'][1], want[0])
+    mean = load_embeddings(os.path.join(H5, 'embeddings_ref_format.h5'), aggregate_mode='mean')
+    np.testing.assert_allclose(mean['speaker_embedding'][2], (want[2] + want[4]) / 2, rtol=1e-6)
+    # and feeds select_embedding with its filters
+    np.testing.assert_array_equal(select_embedding(table, mode=0, id='alice'), want[3])
+    np.testing.assert_allclose(select_embedding(table, mode='mean', id='bob'), (want[2] + want[4]) / 2, rtol=1e-6)
+    assert load_embeddings(os.path.join(H5, 'nothing_here')) is None
+
+
+def test_embeddings_csv_npy_pkl_roundtrip_and_model_directory(tmp_path):
+    import pandas as pd
+    from text_to_speech_amd.embeddings import load_embeddings, save_embeddings
+    from text_to_speech_amd.tacotron2 import SV2TTSTacotron2
+    rng = np.random.default_rng(0)
+    vecs = rng.standard_normal((3, 8)).astype(np.float32)
+    table = pd.DataFrame({'id': ['a', 'b', 'a'], 'embedding': list(vecs)})
+    for ext in ('.csv', '.pkl'):
+        f = save_embeddings('voices' + ext, table, directory=str(tmp_path / ext[1:]))
+        back = load_embeddings(f)
+        assert list(back['id']) == ['a', 'b', 'a']
+        np.testing.assert_allclose(np.stack(back['embedding'].values), vecs, rtol=1e-6)
+    f = save_embeddings('m', vecs, directory=str(tmp_path / 'npy'))
+    assert f.endswith('.npy')
+    np.testing.assert_array_equal(load_embeddings(f[:-4]), vecs)                   # found without the extension
+    # a model directory with a single embeddings file, as the reference keeps it
+    d = tmp_path / 'sv2tts' / 'embeddings'
+    save_embeddings('embeddings.csv', table, directory=str(d))
+    model = SV2TTSTacotron2(lambda *a, **k: None, lang='en', embeddings_dir=str(d), embedding_dim=8)
+    np.testing.assert_allclose(model.select_embedding(1), vecs[1], rtol=1e-6)
+    np.testing.assert_allclose(model.select_embedding({'mode': 'mean', 'id': 'a'}), (vecs[0] + vecs[2]) / 2, rtol=1e-5)

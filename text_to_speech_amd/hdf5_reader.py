@@ -7,10 +7,12 @@ validated against files produced by the real libhdf5 (h5py 3.3 / HDF5 1.10.6; `t
 
 Supported: superblock versions 0-3; object headers version 1 and 2 (with continuation blocks); old-style groups (symbol
 table: v1 B-tree + local heap + SNOD nodes) and new-style groups with compact link messages; datasets of fixed-point and
-floating-point type (little or big endian; IEEE half / single / double and bfloat16) in compact, contiguous or chunked
-(v1 B-tree; layout version 4: single-chunk and implicit index) layout; deflate / shuffle / fletcher32 filters.
-Not supported (clear `H5Error`): dense link storage (fractal heaps), v2 B-tree / array chunk indexes, compound / string /
-variable-length / reference types, external or virtual storage, soft / external links (skipped while walking).
+floating-point type (little or big endian; IEEE half / single / double and bfloat16) and of string type (fixed length, or
+variable length through global heap collections -- what h5py's `string_dtype()` writes; returned as object arrays of `str`)
+in compact, contiguous or chunked (v1 B-tree; layout version 4: single-chunk and implicit index) layout; deflate / shuffle /
+fletcher32 filters.
+Not supported (clear `H5Error`): dense link storage (fractal heaps), v2 B-tree / array chunk indexes, compound /
+variable-length sequence / reference types, external or virtual storage, soft / external links (skipped while walking).
 """
 from __future__ import annotations
 
@@ -56,9 +58,10 @@ class _Msg:
 class H5Dataset:
     """Shape / dtype are parsed eagerly; `read()` materialises the array."""
 
-    def __init__(self, file, path, shape, dtype, bfloat16, layout, filters):
+    def __init__(self, file, path, shape, dtype, bfloat16, layout, filters, string=None):
         self.file, self.path, self.shape, self.dtype = file, path, tuple(shape), dtype
         self._bf16, self._layout, self._filters = bfloat16, layout, filters
+        self._string = string                    # None | 'fixed' (dtype S<n>) | 'vlen' (dtype V16: length + global heap id)
 
     def __repr__(self):
         return f'H5Dataset({self.path!r}, shape={self.shape}, dtype={self.dtype})'
@@ -87,6 +90,22 @@ class H5Dataset:
         return self._finish(np.frombuffer(raw, dtype=self.dtype, count=n).reshape(self.shape))
 
     def _finish(self, a):
+        if self._string == 'fixed':
+            flat = [bytes(x).split(b'\0', 1)[0].decode('utf-8', 'replace') for x in a.reshape(-1)]
+            out = np.empty(len(flat), dtype=object)
+            out[:] = flat
+            return out.reshape(a.shape)
+        if self._string == 'vlen':
+            O = self.file._O
+            raw = np.ascontiguousarray(a).view(np.uint8).reshape(-1, 8 + O)
+            out = np.empty(len(raw), dtype=object)
+            for i, e in enumerate(raw):
+                e = e.tobytes()
+                n = int.from_bytes(e[:4], 'little')
+                addr = self.file._addr(e[4:4 + O])
+                idx = int.from_bytes(e[4 + O:8 + O], 'little')
+                out[i] = '' if addr is None or n == 0 else self.file._global_heap_object(addr, idx)[:n].decode('utf-8', 'replace')
+            return out.reshape(a.shape)
         if self._bf16:
             a = (a.astype(np.uint32) << 16).view(np.float32)
         if a.dtype.byteorder == '>':
@@ -370,6 +389,28 @@ class H5File:
                                   "`h5repack --low=0 --high=0 in.h5 out.h5`")
         return links
 
+    # -- global heap (variable-length data) -----------------------------------------------------------------------------
+    def _global_heap_object(self, addr, index):
+        L = self._L
+        head = bytes(self._bytes(addr, 8 + L))
+        if head[:4] != b'GCOL' or head[4] != 1:
+            raise H5Error('bad global heap collection')
+        size = int.from_bytes(head[8:8 + L], 'little')
+        p, end = addr + 8 + L, addr + size
+        guard = 0
+        while p + 8 + L <= end:
+            guard += 1
+            if guard > 1 << 20:
+                break
+            h = bytes(self._bytes(p, 8 + L))
+            idx, osz = h[0] | h[1] << 8, int.from_bytes(h[8:8 + L], 'little')
+            if idx == 0:
+                break                                                     # free space: end of the used part
+            if idx == index:
+                return bytes(self._bytes(p + 8 + L, osz))
+            p += 8 + L + (osz + 7) // 8 * 8
+        raise H5Error(f'global heap object {index} not found in the collection at {addr}')
+
     # -- datasets ------------------------------------------------------------------------------------------------------
     def _dataspace(self, data):
         d, L = bytes(data), self._L
@@ -399,7 +440,13 @@ class H5File:
             if (size, exp_size) not in ((2, 5), (4, 8), (8, 11)):
                 raise H5Error(f'{path}: unsupported floating-point format (size {size}, exponent bits {exp_size})')
             return np.dtype(f'{order}f{size}'), False
-        raise H5Error(f'{path}: unsupported datatype class {cls} (only fixed- and floating-point datasets are read)')
+        if cls == 3:
+            if size <= 0 or size > 1 << 20:
+                raise H5Error(f'{path}: implausible string size {size}')
+            return np.dtype(f'S{size}'), 'fixed'
+        if cls == 9 and (bits0 & 0x0f) == 1:                              # variable-length STRING (not a sequence)
+            return np.dtype(f'V{8 + self._O}'), 'vlen'
+        raise H5Error(f'{path}: unsupported datatype class {cls} (numeric and string datasets are read)')
 
     def _filters(self, data, path):
         d = bytes(data)
@@ -498,12 +545,13 @@ class H5File:
 
     def _dataset(self, msgs, path):
         shape = dtype = layout_msg = None
-        filters, bf16 = [], False
+        filters, bf16, string = [], False, None
         for m in msgs:
             if m.type == 0x01:
                 shape = self._dataspace(m.data)
             elif m.type == 0x03:
-                dtype, bf16 = self._datatype(m.data, path)
+                dtype, kind = self._datatype(m.data, path)
+                bf16, string = kind is True, kind if isinstance(kind, str) else None
             elif m.type == 0x08:
                 layout_msg = m.data
             elif m.type == 0x0B:
@@ -511,7 +559,7 @@ class H5File:
         if shape is None or dtype is None or layout_msg is None:
             raise H5Error(f'{path}: incomplete dataset header')
         layout = self._layout(layout_msg, shape, dtype.itemsize, bool(filters), path)
-        return H5Dataset(self, path, shape, dtype, bf16, layout, filters)
+        return H5Dataset(self, path, shape, dtype, bf16, layout, filters, string)
 
     # -- public --------------------------------------------------------------------------------------------------------
     @_guard

@@ -320,9 +320,18 @@ class SV2TTSTacotron2(Tacotron2):
     mode ('mean' when `use_label_embedding`, else 'random'), an int -> that row, a str -> that mode, a dict ->
     `select_embedding(**dict)`; the reference's default is `embeddings=0`, the first row."""
 
-    def __init__(self, compiled_infer, lang='fr', *, embeddings=None, embedding_dim=256, use_label_embedding=False,
-                 encoder_name=None, **kwargs):
+    def __init__(self, compiled_infer, lang='fr', *, embeddings=None, embeddings_dir=None, embedding_dim=256,
+                 use_label_embedding=False, encoder_name=None, **kwargs):
         super().__init__(compiled_infer, lang=lang, **kwargs)
+        # `embeddings`: the collection itself (matrix / DataFrame) or a file of one (csv / npy / pkl / the reference's h5);
+        # `embeddings_dir`: the model's `<name>/embeddings` directory, searched like sv2tts_tacotron2.py:53-67 (the only
+        # file in it, else `embeddings.<ext>`)
+        if embeddings is None and embeddings_dir is not None and os.path.isdir(embeddings_dir):
+            found = sorted(os.listdir(embeddings_dir))
+            embeddings = os.path.join(embeddings_dir, found[0] if len(found) == 1 else 'embeddings')
+        if isinstance(embeddings, str):
+            from .embeddings import load_embeddings
+            embeddings = load_embeddings(embeddings)
         self.embeddings = embeddings
         self.embedding_dim = embedding_dim
         self.use_label_embedding = use_label_embedding
