@@ -502,3 +502,37 @@ def test_embeddings_csv_npy_pkl_roundtrip_and_model_directory(tmp_path):
     model = SV2TTSTacotron2(lambda *a, **k: None, lang='en', embeddings_dir=str(d), embedding_dim=8)
     np.testing.assert_allclose(model.select_embedding(1), vecs[1], rtol=1e-6)
     np.testing.assert_allclose(model.select_embedding({'mode': 'mean', 'id': 'a'}), (vecs[0] + vecs[2]) / 2, rtol=1e-5)
+
+
+# ---- tokenizer.json of a shipped model (reference: utils/text/tokenizer.py:54-213,394-452,661-702) ------------------------------
+def test_tokenizer_config_file_roundtrip_and_reference_index_rules(tmp_path):
+    import json
+    from text_to_speech_amd.text import CharTokenizer, en_symbols
+    base = CharTokenizer('en')
+    f = base.save(str(tmp_path / 'tokenizer.json'))
+    again = CharTokenizer.load_from_file(f)
+    text = 'Dr. Smith paid $3.50 for 2 apples, i.e. too much!'
+    assert again.clean_text(text) == base.clean_text(text)
+    np.testing.assert_array_equal(again.encode(text), base.encode(text))
+    assert again.vocab_size == base.vocab_size == len(en_symbols) and again.lang == 'en'
+
+    # a config as the reference writes it: cleaners with keyword arguments, an unknown-token, sos / eos in use, specials first
+    cfg = {'name': 'Tokenizer', 'vocab': list('_abc '), 'level': 0, 'template': None, 'lstrip': True, 'rstrip': True,
+           'cleaners': [{'name': 'french_cleaners', 'to_lowercase': False}], 'split_pattern': None, 'bpe_pairs': None,
+           'byte_encoder': None, 'bpe_end_of_word': None, 'pad_token': '_', 'sos_token': '<s>', 'eos_token': '</s>',
+           'sep_token': None, 'ukn_token': '?', 'mask_token': None, 'additional_tokens': {}, 'sub_word_prefix': '',
+           'use_sos_and_eos': True, 'add_special_tokens_at_end': False}
+    p = tmp_path / 'fr.json'
+    p.write_text(json.dumps(cfg), encoding='utf-8')
+    tok = CharTokenizer.load_from_file(str(p))
+    # __build_indexes: specials (ukn, sos, eos) first, then the vocabulary
+    assert tok.symbols == ['?', '<s>', '</s>', '_', 'a', 'b', 'c', ' '] and tok.lang == 'fr'
+    ids = tok.encode('  ab Zc ').tolist()                           # stripped; 'Z' is not lower-cased, so it is unknown
+    assert ids == [1, 4, 5, 7, 0, 6, 2]
+    cfg['use_sos_and_eos'], cfg['ukn_token'], cfg['add_special_tokens_at_end'] = False, None, True
+    tok = CharTokenizer.from_config(cfg)
+    assert tok.symbols == list('_abc ') and tok.encode('ab Zc').tolist() == [1, 2, 4, 3]       # unknown dropped, no sos / eos
+
+    for bad in ({**cfg, 'level': 1}, {**cfg, 'bpe_pairs': [['a', 'b']]}, {**cfg, 'cleaners': ['no_such_cleaner']}):
+        with pytest.raises(ValueError):
+            CharTokenizer.from_config(bad)

@@ -34,6 +34,8 @@ class Tacotron2:
 
     def __init__(self, compiled_infer, lang='en', tokenizer=None, pred_dir=None):
         self.compiled_infer = compiled_infer
+        if isinstance(tokenizer, str):                           # a shipped model's `saving/tokenizer.json`
+            tokenizer = CharTokenizer.load_from_file(tokenizer, lang=lang)
         self.tokenizer = tokenizer or CharTokenizer(lang)
         self.pred_dir = pred_dir or os.path.join('pretrained_models', 'tacotron2_hip', 'outputs')
 

@@ -567,6 +567,82 @@ class CharTokenizer:
         self.symbols = en_symbols if lang == 'en' else fr_symbols
         self.index = {s: i for i, s in enumerate(self.symbols)}
         self.cleaner = {'en': english_cleaners, 'fr': french_cleaners, 'be': belgian_cleaners}.get(lang, french_cleaners)
+        self.cleaners = [self.cleaner.__name__]
+        self.pad_token = _pad
+        self.sos_token = self.eos_token = self.ukn_token = None
+        self.use_sos_and_eos = False
+
+    # ---- the shipped models carry their own vocabulary: `<model>/saving/tokenizer.json` = Tokenizer.get_config()
+    #      (utils/text/tokenizer.py:661-702); a fresh model takes get_symbols(lang) instead (utils/text/__init__.py:93-96)
+    @classmethod
+    def from_config(cls, config, lang=None):
+        """Builds the tokenizer from a reference `Tokenizer` config (character level only).  Ids follow
+        `Tokenizer.__build_indexes` (tokenizer.py:183-213): the vocabulary in order, the special tokens that are in use
+        (sep / ukn, sos / eos when `use_sos_and_eos`, additional tokens) before or after it; cleaners by name, with their
+        keyword arguments (`{'name': 'french_cleaners', 'to_lowercase': False}` or `(name, kwargs)`)."""
+        level = config.get('level', 0)
+        if str(level).lower() not in ('0', 'char', 'tokenizerlevel.char'):
+            raise ValueError(f'only character-level tokenizers are supported (the TTS models), got level {level!r}')
+        if config.get('bpe_pairs') or config.get('split_pattern'):
+            raise ValueError('BPE / pattern-split tokenizers are not part of the TTS path')
+        self = cls.__new__(cls)
+        self.lstrip, self.rstrip = bool(config.get('lstrip', False)), bool(config.get('rstrip', False))
+        self.pad_token = config.get('pad_token', '')
+        self.sos_token, self.eos_token = config.get('sos_token'), config.get('eos_token')
+        self.ukn_token = config.get('ukn_token')
+        self.use_sos_and_eos = bool(config.get('use_sos_and_eos', False))
+        specials = [config.get(k) for k in ('sep_token', 'ukn_token') if config.get(k) is not None]
+        if self.use_sos_and_eos:
+            specials += [t for t in (self.sos_token, self.eos_token) if t is not None]
+        extra = config.get('additional_tokens') or []
+        specials += list(extra.values()) if isinstance(extra, dict) else ([extra] if isinstance(extra, str) else list(extra))
+        vocab = list(config['vocab'])
+        order = (vocab + specials) if config.get('add_special_tokens_at_end', True) else (specials + vocab)
+        self.index = {}
+        for sym in order:
+            self.index.setdefault(sym, len(self.index))
+        self.symbols = sorted(self.index, key=self.index.get)
+        known = {'english_cleaners': english_cleaners, 'french_cleaners': french_cleaners, 'belgian_cleaners': belgian_cleaners,
+                 'complete_cleaners': complete_cleaners}
+        self.cleaners, fns = list(config.get('cleaners') or []), []
+        for c in self.cleaners if isinstance(self.cleaners, (list, tuple)) else [self.cleaners]:
+            name, kw = (c, {}) if isinstance(c, str) else (c[0], dict(c[1] or {})) if isinstance(c, (list, tuple)) \
+                else (c['name'], {k: v for k, v in c.items() if k != 'name'})
+            if name not in known:
+                raise ValueError('Unknown cleaner : {}'.format(name))
+            fns.append((known[name], kw))
+        names = ' '.join(n.__name__ for n, _ in fns)
+        self.lang = lang or ('en' if 'english' in names else 'be' if 'belgian' in names else 'fr' if 'french' in names
+                             else fns[0][1].get('lang', 'en') if fns else 'en')
+
+        def run(text, **kwargs):
+            for fn, kw in fns:
+                args = {**kw, **kwargs}
+                if fn is complete_cleaners:
+                    args.setdefault('lang', self.lang)
+                    text = fn(text, args.pop('lang'), **args)
+                else:
+                    text = fn(text, **args)
+            return text
+        self.cleaner = run
+        return self
+
+    @classmethod
+    def load_from_file(cls, filename, lang=None):
+        import json
+        with open(filename, encoding='utf-8') as fh:
+            return cls.from_config(json.load(fh), lang=lang)
+
+    def get_config(self):
+        return {'name': 'Tokenizer', 'vocab': [s for s in self.symbols], 'level': 0, 'lstrip': self.lstrip, 'rstrip': self.rstrip,
+                'cleaners': self.cleaners, 'pad_token': self.pad_token, 'sos_token': self.sos_token, 'eos_token': self.eos_token,
+                'ukn_token': self.ukn_token, 'use_sos_and_eos': self.use_sos_and_eos, 'add_special_tokens_at_end': True}
+
+    def save(self, filename):
+        import json
+        with open(filename, 'w', encoding='utf-8') as fh:
+            json.dump(self.get_config(), fh, indent=4, ensure_ascii=False)
+        return filename
 
     @property
     def vocab_size(self):
@@ -585,5 +661,12 @@ class CharTokenizer:
     def encode(self, text, cleaned=False):
         if not cleaned:
             text = self.clean_text(text)
-        ids = [self.index[c] for c in text if c in self.index and c != _pad]
+        ukn = self.index.get(self.ukn_token, -1) if self.ukn_token is not None else -1
+        ids = [self.index.get(c, ukn) for c in text if c != self.pad_token]
+        ids = [i for i in ids if i != -1]                        # unknown characters are dropped unless there is an ukn token
+        if self.use_sos_and_eos:                                 # tokenizer.py:447-450
+            if self.sos_token in self.index and (not ids or ids[0] != self.index[self.sos_token]):
+                ids.insert(0, self.index[self.sos_token])
+            if self.eos_token in self.index and (not ids or ids[-1] != self.index[self.eos_token]):
+                ids.append(self.index[self.eos_token])
         return np.asarray(ids, dtype=np.int32)
