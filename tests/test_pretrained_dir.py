@@ -1,0 +1,93 @@
+"""Opening a reference model directory (pretrained_models/<name>/): checkpoint choice, config / tokenizer / embeddings
+discovery and the one-time weight conversion -- the CPU part of text_to_speech_amd.pretrained (the engine step needs a GPU).
+Layout: models/interfaces/base_model.py:127-137,752-758; custom_train_objects/checkpoint_manager.py:23-26,70-98,137-143."""
+import json
+import os
+import shutil
+import time
+
+import numpy as np
+import pytest
+
+from test_hdf5_reader import H5
+from test_keras_h5 import TINY
+from text_to_speech_amd import pretrained
+from text_to_speech_amd.weights import load_ttsw, tacotron2_manifest, waveglow_manifest
+
+
+def make_dir(root, class_name, ckpt_fixture, *, state=None, config=None, ckpt_name='ckpt-0002.weights.h5'):
+    d = root / class_name.lower()
+    (d / 'saving').mkdir(parents=True)
+    (d / 'config.json').write_text(json.dumps({'class_name': class_name, 'config': {'name': d.name, 'lang': 'fr', **(config or {})}}))
+    shutil.copy(os.path.join(H5, ckpt_fixture), d / 'saving' / ckpt_name)
+    if state is not None:
+        (d / 'saving' / 'checkpoint.json').write_text(json.dumps(state))
+    return d
+
+
+def test_checkpoint_choice_follows_the_manager_state(tmp_path):
+    save = tmp_path / 'saving'
+    save.mkdir()
+    for n in (0, 1, 2):
+        (save / f'ckpt-{n:04d}.weights.h5').write_bytes(b'x')
+        os.utime(save / f'ckpt-{n:04d}.weights.h5', (1000 + n, 1000 + n))
+    (save / 'best.weights.h5').write_bytes(b'x')
+    os.utime(save / 'best.weights.h5', (900, 900))
+    entries = [{'epoch': n, 'step': 10 * n, 'counter': n} for n in (0, 1, 2)]
+    pick = lambda state: os.path.basename(pretrained.find_checkpoint(str(save)))
+    (save / 'checkpoint.json').write_text(json.dumps({'counter': 3, 'loaded': -1, 'checkpoints': entries, 'best_checkpoint': {}}))
+    assert pick(None) == 'ckpt-0002.weights.h5'
+    (save / 'checkpoint.json').write_text(json.dumps({'counter': 3, 'loaded': 1, 'checkpoints': entries}))
+    assert pick(None) == 'ckpt-0001.weights.h5'
+    (save / 'checkpoint.json').write_text(json.dumps({'counter': 3, 'loaded': 'best', 'checkpoints': entries}))
+    assert pick(None) == 'best.weights.h5'
+    (save / 'checkpoint.json').write_text('{ not json')
+    assert pick(None) == 'ckpt-0002.weights.h5'                    # newest file when the state is unreadable
+    with pytest.raises(FileNotFoundError):
+        pretrained.find_checkpoint(str(tmp_path / 'nothing'))
+
+
+def test_tacotron2_directory_is_converted_once_and_described(tmp_path):
+    d = make_dir(tmp_path, 'Tacotron2', 'keras_tacotron2_walk.weights.h5',
+                 state={'counter': 3, 'loaded': -1, 'checkpoints': [{'epoch': 4, 'step': 99, 'counter': 2}]},
+                 config={'tokenizer': 'pretrained_models/elsewhere/saving/tokenizer.json'})
+    from text_to_speech_amd.text import CharTokenizer
+    CharTokenizer('fr').save(str(d / 'saving' / 'tokenizer.json'))
+    out, info = pretrained.convert_model_dir(str(d), cfg=TINY['tacotron2'])
+    assert info['model'] == 'tacotron2' and info['lang'] == 'fr' and info['speaker_embedding_dim'] == 0
+    assert info['tokenizer_file'] == str(d / 'saving' / 'tokenizer.json')        # the stored path does not exist here
+    assert out == str(d / 'saving' / 'ckpt-0002.ttsw')
+    assert list(load_ttsw(out)) == list(tacotron2_manifest(TINY['tacotron2']))
+    stamp = os.path.getmtime(out)
+    time.sleep(0.02)
+    assert pretrained.convert_model_dir(str(d), cfg=TINY['tacotron2'])[0] == out and os.path.getmtime(out) == stamp   # cached
+    os.utime(d / 'saving' / 'ckpt-0002.weights.h5')                 # a newer checkpoint invalidates the cache
+    time.sleep(0.02)
+    pretrained.convert_model_dir(str(d), cfg=TINY['tacotron2'])
+    assert os.path.getmtime(out) > stamp
+
+
+def test_waveglow_and_sv2tts_directories(tmp_path):
+    d = make_dir(tmp_path, 'WaveGlow', 'keras_waveglow_attrs.weights.h5', ckpt_name='best.weights.h5',
+                 state={'counter': 1, 'loaded': 'best', 'checkpoints': [{'epoch': 0, 'step': 0, 'counter': 0}]})
+    out, info = pretrained.convert_model_dir(str(d), cfg=TINY['waveglow'])
+    assert info['model'] == 'waveglow' and info['tokenizer_file'] is None and out.endswith('best.ttsw')
+    assert list(load_ttsw(out)) == list(waveglow_manifest(TINY['waveglow']))
+    s = make_dir(tmp_path, 'SV2TTSTacotron2', 'keras_tacotron2_attrs.weights.h5', config={'embedding_dim': 256})
+    (s / 'embeddings').mkdir()
+    shutil.copy(os.path.join(H5, 'embeddings_ref_format.h5'), s / 'embeddings' / 'embeddings.h5')
+    info = pretrained.read_model_dir(str(s))
+    assert info['speaker_embedding_dim'] == 256 and info['embeddings_dir'] == str(s / 'embeddings')
+    assert info['checkpoint'].endswith('ckpt-0002.weights.h5')     # no state file: the newest checkpoint
+    # the full-size SV2TTS manifest does not fit the tiny file: refused with the tensor named, nothing cached
+    with pytest.raises(ValueError, match='converted shape'):
+        pretrained.convert_model_dir(str(s))
+    assert not os.path.exists(str(s / 'saving' / 'ckpt-0002.ttsw'))
+
+
+def test_foreign_directories_are_refused(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        pretrained.read_model_dir(str(tmp_path))
+    d = make_dir(tmp_path, 'Whisper', 'keras_waveglow_attrs.weights.h5')
+    with pytest.raises(ValueError, match='not a model of the TTS path'):
+        pretrained.read_model_dir(str(d))
