@@ -226,5 +226,26 @@ def main():
         print(name, os.path.getsize(os.path.join(HERE, name)))
 
 
+def write_full_size(out_dir, walk=False):
+    """Full-size Tacotron2 checkpoint (seeded synthetic weights) in the Keras layout + the same tensors as .npz: used by the
+    GPU test of `pretrained.load_model` (tests/test_pretrained_gpu.py), which runs this file with the h5py interpreter."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+    from text_to_speech_amd.config import Tacotron2Config
+    from text_to_speech_amd.weights import synth_tacotron2
+    w = synth_tacotron2(Tacotron2Config(), seed=4321)
+    table = keras_tacotron2_paths(walk)
+    assert sorted(table) == sorted(w)
+    os.makedirs(out_dir, exist_ok=True)
+    with h5py.File(os.path.join(out_dir, 'ckpt-0000.weights.h5'), 'w') as f:
+        for tensor, path in table.items():
+            f.create_dataset(path, data=w[tensor])
+    np.savez(os.path.join(out_dir, 'tensors.npz'), **{k.replace('/', '|'): v for k, v in w.items()})
+
+
 if __name__ == '__main__':
-    main()
+    import sys
+    if len(sys.argv) >= 3 and sys.argv[1] == '--full-tacotron2':
+        write_full_size(sys.argv[2], walk=len(sys.argv) > 3 and sys.argv[3] == 'walk')
+    else:
+        main()
