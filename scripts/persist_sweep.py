@@ -36,6 +36,10 @@ print(f'B={B}: all sentinel polls: {base:.2f} us/step', flush=True)
 # candidate delays in 10-ns ticks, per hop (A, B, C, D, E, F), around the anchors' expected arrival
 cands = {0: (55, 65, 75), 1: (80, 90, 100, 110, 120), 2: (150, 165, 180, 195, 210, 225),
          3: (70, 85), 4: (50, 58, 66, 74, 82), 5: (120, 135, 150, 165, 180, 195)}
+if os.environ.get('SWEEP_CANDS'):                  # e.g. '{"1": [180, 240, 300], "4": [120, 170, 220]}': only these hops are swept
+    import json
+    cands = {h: () for h in range(6)}
+    cands.update({int(k): tuple(v) for k, v in json.loads(os.environ['SWEEP_CANDS']).items()})
 cur = base
 for sweep in range(2):
     for hop in (4, 1, 5, 2, 0, 3):
