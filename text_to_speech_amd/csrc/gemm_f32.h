@@ -84,6 +84,8 @@ struct GemmArgs {
     // ---- phase-major mode (0 = off)
     int phase_rows;                 // rows per phase block (multiple of the M tile); M = 32 * phase_rows
     int frames;                     // real frame rows per phase block (rows f >= frames are padding)
+    int phase_step;                 // > 0: tile order that keeps the three conv taps' phase blocks together on one XCD
+                                    // (the tap offset in phases, a power of two <= 16; see the kernel's tile order)
     const float* Bt2;               // optional second weight matrix for the sequential segments [phase][N][ldb2]
     long long ldb2;
     long long strideB2p;            // per-phase stride of Bt2 (0: shared)
@@ -195,8 +197,23 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int mt = (slot / numNt) * 8 + xcd;
+    int mt = (slot / numNt) * 8 + xcd;
     const int nt = slot % numNt;
+    if (g.phase_rows > 0 && g.phase_step > 0) {
+        // Conv taps of a tile (phase p, frame range F) read the activation rows of the tiles (p - s, F) and (p + s, F),
+        // s = phase_step: with M tiles dealt round-robin to the XCDs every activation row was fetched from HBM three times
+        // (once per reading tile, each into a different L2).  Here every XCD walks its own contiguous share of the sequence
+        // "F outer, then the phases along the orbits of +s": p = r, r + s, r + 2 s, ... for r = 0 .. s - 1, so that the tiles
+        // in flight on an XCD at any time (~8) read a sliding window of activation rows that its L2 (4 MB = 8 row tiles) holds.
+        const int tpp = g.phase_rows / BM;                         // frame tiles per phase block
+        const int seq = xcd * ((numMt + 7) >> 3) + slot / numNt;   // this XCD's chunk of the sequence
+        if (seq >= numMt) return;
+        const int ft = seq >> 5, i = seq & 31;                     // 32 phases per frame range
+        const int per = 32 / g.phase_step;                         // orbit length
+        const int ph = (i % per) * g.phase_step + i / per;
+        mt = ph * tpp + ft;
+        if (ft >= tpp) return;
+    }
     if (mt >= numMt) return;
     const int m0 = mt * BM, n0 = nt * BN;
     const long long z = blockIdx.z;

@@ -789,6 +789,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
             g.L = T;                                   // sequence bounds are tested on the frame index inside a batch item
             g.phase_rows = PR;
             g.frames = BT;
+            g.phase_step = d < 32 ? d : 1;             // taps at +-d groups: another phase block for d < 32, else +-d / 32 frames
             g.nseg = 7;
             g.bias = ly.in_bias;
             g.mode = EPI_GATE;
