@@ -126,3 +126,28 @@ def infer(mel, w, cfg, z=None, sigma=1.0, dtype=np.float32, return_intermediates
             inter[f'audio_after_flow_{k}'] = audio.copy()
     res = audio.reshape(B, -1)
     return (res, inter) if return_intermediates else res
+
+
+def forward_flow(audio, mel, w, cfg, dtype=np.float64):
+    """The generative flow in its FORWARD (audio -> z) direction, which the reference does not contain (its `call` is `infer`,
+    waveglow_arch.py:241-242): written from the published model (Prenger et al. 2018, section 2; each flow step = invertible
+    1x1 convolution, then the affine coupling a1 <- exp(s) a1 + b with (b, s) = WN(a0, spect); n_early_size channels leave
+    every n_early_every flows).  Used only to test that `infer` really is its inverse.  audio [B, T*256] -> z in the layout
+    `infer` consumes: [final n_remaining | early outputs, latest first]."""
+    w = {k: v.astype(dtype) for k, v in w.items() if k.startswith('waveglow/')}
+    spect = regroup(upsample(np.asarray(mel, dtype=dtype), w['waveglow/upsample/kernel'], w['waveglow/upsample/bias'],
+                             cfg.upsample_stride), cfg.n_group)
+    B, L, _ = spect.shape
+    a = np.asarray(audio, dtype=dtype).reshape(B, L, cfg.n_group)
+    early = []
+    for k in range(cfg.n_flows):
+        if k % cfg.n_early_every == 0 and k > 0:
+            early.append(a[:, :, :cfg.n_early_size])
+            a = a[:, :, cfg.n_early_size:]
+        a = a @ w[f'waveglow/invertible_conv-{k}/conv/kernel'][0]            # Conv1D(k = 1), Keras kernel [1, in, out]
+        n_half = a.shape[2] // 2
+        a0, a1 = a[:, :, :n_half], a[:, :, n_half:]
+        out = wn_block(a0, spect, w, f'waveglow/block-{k}', cfg.n_layers, cfg.n_channels)
+        a1 = np.exp(out[:, :, n_half:]) * a1 + out[:, :, :n_half]
+        a = np.concatenate([a0, a1], axis=2)
+    return np.concatenate([a] + early[::-1], axis=2)

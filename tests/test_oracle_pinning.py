@@ -83,3 +83,21 @@ def test_decoder_lengths_rule_on_scripted_stop(taco_cfg):
     assert np.all(o.decoder_output[:, steps:] == 0)                # loop ended once all rows had fired
     np.testing.assert_allclose(o.attention_weights[:, :steps].sum(-1), 1.0, atol=1e-5)
     assert np.all(o.attention_weights[1, :, 25:] == 0)             # masked tokens: exactly zero weight
+
+
+def test_waveglow_infer_inverts_the_published_forward_flow():
+    """`infer` must undo the generative flow of the WaveGlow paper step by step: channel order of the early outputs, which
+    half the coupling transforms, the direction of the 1x1 inverse, (a1 - b) / exp(s).  The forward direction is written from
+    the publication (oracle/waveglow_ref.forward_flow); float64 keeps the round trip tight."""
+    from oracle import waveglow_ref
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import WaveGlowConfig
+    cfg = WaveGlowConfig(n_channels=32, n_layers=3)
+    w = weights.synth_waveglow(cfg, seed=5, end_scale=0.3)
+    rng = np.random.default_rng(2)
+    mel = rng.uniform(-11.5, 1.2, (2, 3, 80))
+    audio = rng.uniform(-1, 1, (2, 3 * 256))
+    z = waveglow_ref.forward_flow(audio, mel, w, cfg)
+    assert z.shape == (2, 96, 8) and np.abs(z - audio.reshape(2, 96, 8)).max() > 0.1      # the flow does something
+    back = waveglow_ref.infer(mel, w, cfg, z=z, sigma=1.0, dtype=np.float64)
+    np.testing.assert_allclose(back, audio, atol=1e-9)

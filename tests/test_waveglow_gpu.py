@@ -55,6 +55,21 @@ def test_waveglow_parity_with_four_times_less_end_attenuation(wg_cfg):
         eng.close()
 
 
+def test_waveglow_hip_inverts_the_published_forward_flow(gpu_engine, wg_weights, wg_cfg):
+    """Round trip through the model itself: z = forward flow of a waveform (written from the WaveGlow paper, float64, CPU;
+    oracle/waveglow_ref.forward_flow), then the HIP `infer` must give the waveform back.  Independent of the oracle's `infer`."""
+    from oracle import waveglow_ref
+    rng = np.random.default_rng(21)
+    mel = rng.uniform(-11.5, 1.2, (2, 5, 80)).astype(np.float32)
+    audio = rng.uniform(-0.9, 0.9, (2, 5 * 256)).astype(np.float32)
+    z = waveglow_ref.forward_flow(audio, mel, wg_weights, wg_cfg).astype(np.float32)
+    for prec in ('f32', 'f16x3'):
+        out = gpu_engine.waveglow_infer(mel, z=z, sigma=1.0, precision=prec)
+        err = rms(out - audio)
+        print(f'round trip {prec}: rms_err={err:.3e} max_err={np.abs(out - audio).max():.3e}')
+        assert err <= RMS_TOL
+
+
 def test_waveglow_deterministic_zero_noise(gpu_engine, wg_weights, wg_cfg):
     """z=None is the reference's deterministic=True path (zeros), waveglow_arch.py:264-267,293-296."""
     from oracle import waveglow_ref
