@@ -198,3 +198,33 @@ def test_long_inputs_cover_every_attention_path(gpu_engine, taco_weights, taco_c
     out = gpu_engine.tacotron2_infer(tok, max_len=6, early_stopping=False, **gkw)
     _check(out, ref)
     assert np.all(out.attention_weights[1, :, lens[1]:] == 0)
+
+
+def test_padding_and_batch_composition_do_not_change_a_row(gpu_engine):
+    """Properties the reference's masking guarantees, independent of any oracle (location_sensitive_attention.py:96-102,
+    tacotron2_arch.py:625-627): a sentence gives the same frames whether its token row is padded to 40 or to 120 positions,
+    and whether it is decoded alone or next to other sentences -- the padded positions get exactly zero attention."""
+    rng = np.random.default_rng(9)
+    real = rng.integers(1, 148, 37).astype(np.int32)
+    T = 24
+    masks = (rng.random((3, T, 2, 256)) >= 0.5).astype(np.float32) * 2.0
+    outs = []
+    for Tin in (40, 120):
+        tok = np.zeros((1, Tin), np.int32)
+        tok[0, :37] = real
+        outs.append(gpu_engine.tacotron2_infer(tok, max_len=T, early_stopping=False, prenet_masks=masks[:1]))
+    a, b = outs
+    assert np.abs(a.mel - b.mel).max() <= 2e-5
+    assert (b.attention_weights[0, :, 37:] == 0).all() and (a.attention_weights[0, :, 37:] == 0).all()
+    np.testing.assert_allclose(a.attention_weights[0, :, :37], b.attention_weights[0, :, :37], atol=2e-6)
+    np.testing.assert_allclose(b.attention_weights[0].sum(-1), 1.0, atol=1e-5)
+    # the same sentence as row 1 of a batch of three
+    tok3 = np.zeros((3, 64), np.int32)
+    tok3[0, :64] = rng.integers(1, 148, 64)
+    tok3[1, :37] = real
+    tok3[2, :9] = rng.integers(1, 148, 9)
+    m3 = masks.copy()
+    m3[1] = masks[0]
+    c = gpu_engine.tacotron2_infer(tok3, max_len=T, early_stopping=False, prenet_masks=m3)
+    assert np.abs(c.mel[1] - a.mel[0]).max() <= 2e-5
+    assert (c.attention_weights[1, :, 37:] == 0).all() and (c.attention_weights[2, :, 9:] == 0).all()
