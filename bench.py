@@ -269,6 +269,20 @@ def secondary_metrics(eng, dev, rank):
     secs = sum(len(a) for a in audio) / SAMPLE_RATE
     out['pipeline_batch8_f16_audio_seconds_per_s'] = secs / dt
     out['pipeline_batch8_f16_ms'] = dt * 1e3
+    # mel-STFT (rows C1 / C2 of SURVEY 8a): 8 x 204 800 samples, DFT as a windowed real / imaginary basis product + mel + log.
+    # Executed work as written by the reference: 2 * 1024 * 1026 + 2 * 513 * 80 FLOP per frame.
+    wav = torch.from_numpy(np.random.default_rng(9).uniform(-0.5, 0.5, (BATCH, FRAMES * 256)).astype(np.float32)).to(dev)
+    eng.mel_stft(wav)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.mel_stft(wav)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    n_fr = BATCH * (FRAMES + 1)
+    out['mel_stft_batch8_ms'] = dt * 1e3
+    out['mel_stft_audio_seconds_per_s'] = BATCH * FRAMES * 256 / SAMPLE_RATE / dt
+    out['mel_stft_tflops_as_written'] = n_fr * (2.0 * 1024 * 1026 + 2.0 * 513 * 80) / dt / 1e12
     return out
 
 
