@@ -133,7 +133,7 @@ int tts_hip_tacotron2_decode(tts_hip_engine* e, const tts_hip_encoded* encoded, 
 int tts_hip_encoded_free(tts_hip_engine* e, tts_hip_encoded* encoded);
 
 /* How the autoregressive loop (tacotron2_arch.py:710-735, K.while_loop) is executed.  mode 1 (default): one persistent,
- * weight-stationary cooperative kernel for the whole loop when the call shape allows it (batch <= 4, B * Tin small enough
+ * weight-stationary persistent kernel for the whole loop when the call shape allows it (batch <= 4, B * Tin small enough
  * for LDS, a device with >= 256 CUs that can host the whole grid), otherwise -- and always with mode 0 -- one hipGraph of 7
  * kernels per decoder step.  Both give the same results up to fp32 re-association.                                     */
 int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode);

@@ -2,7 +2,7 @@
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   scripts/collect_profiles.sh <tag>        e.g. r01b
 # Outputs land in gpurun_out/prof_<tag>/ ; scripts/summarize_profiles.py turns them into the files kept under profiles/.
-set -uo pipefail   # a profiled process that crashes at exit (seen: SIGSEGV in teardown after the outputs were written) must not stop the collection
+set -euo pipefail
 tag="${1:-r01}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out/prof_$tag"

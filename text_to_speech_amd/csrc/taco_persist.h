@@ -31,7 +31,7 @@ constexpr int PERSIST_MAX_B = 4;
 size_t persist_xch_u64(int B, int Tin);
 // true if this call shape can run on the persistent kernel on the engine's device (batch, LDS footprint, CU count)
 bool persist_applicable(const tts_hip_engine* e, int B, int Tin);
-// Runs the whole decoder loop (all steps, device-side early stop) in ONE cooperative launch on `st`.
+// Runs the whole decoder loop (all steps, device-side early stop) in ONE launch on `st`.
 // Returns TTS_HIP_OK and *steps_run; 1 if the blocks could not all become resident (nothing was modified) or 2 if a hop
 // timed out in mid-loop (outputs partial: the caller re-zeroes them) -- in both cases the caller falls back to the per-step
 // graph; or a negative TTS_HIP_E* code.  Synchronizes `st`.

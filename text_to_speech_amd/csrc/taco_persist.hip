@@ -5,7 +5,7 @@
 // /root/reference/architectures/tacotron2_arch.py:629-689 (loop body), :422-486 (cell), :188-203 (prenet) and
 // architectures/layers/location_sensitive_attention.py:104-186, re-associated as described below.
 //
-// ONE cooperative launch runs the whole loop.  256 blocks x 4 waves; wave w of block b owns unit u = 4 b + w of BOTH
+// ONE launch runs the whole loop.  256 blocks x 4 waves; wave w of block b owns unit u = 4 b + w of BOTH
 // LSTMs and keeps its 4 + 4 gate rows in registers for the entire utterance (fp32: 208 VGPRs per lane), so a step
 // streams no weights at all.  What a step costs instead is the exchange of small vectors between the CUs.  There is no
 // grid barrier (7.7 us on this part): every exchanged value is published as ONE 8-byte (step tag, fp32) agent-scope store
@@ -917,9 +917,16 @@ hipError_t launch_persist(hipStream_t st, const PersistArgs& args, size_t lds) {
     auto kern = decoder_persist_kernel<NBT, KT, HW>;
     static PerDeviceOnce attr;
     if (hipError_t er = set_max_dyn_lds_once((const void*)kern, lds, attr); er != hipSuccess) return er;
-    PersistArgs copy = args;
-    void* kargs[] = {&copy};
-    return hipLaunchCooperativeKernel((const void*)kern, dim3(NBLK), dim3(256), kargs, (unsigned)lds, st);
+    // A plain launch: the kernel never calls grid.sync() -- it has its own start-up rendezvous, which gives up cleanly when
+    // the blocks cannot all be resident -- so the cooperative launch API bought nothing except its occupancy check (done
+    // here), and it makes HIP create a separate cooperative queue whose teardown crashed rocprofv3 at process exit.
+    int per_cu = 0, dev = 0, n_cu = 0;
+    if (hipError_t er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds); er != hipSuccess) return er;
+    if (hipError_t er = hipGetDevice(&dev); er != hipSuccess) return er;
+    if (hipError_t er = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); er != hipSuccess) return er;
+    if ((long long)per_cu * n_cu < NBLK) return hipErrorCooperativeLaunchTooLarge;      // the caller falls back to the per-step graph
+    hipLaunchKernelGGL(kern, dim3(NBLK), dim3(256), lds, st, args);
+    return hipGetLastError();
 }
 
 template <bool HW>

@@ -299,7 +299,7 @@ class HipEngine:
                                         lengths=lengths)
 
     def set_decoder_mode(self, mode: str) -> None:
-        """'persistent' (default: one weight-stationary cooperative kernel for the whole decoder loop when the call shape
+        """'persistent' (default: one weight-stationary persistent kernel for the whole decoder loop when the call shape
         allows it) or 'graph' (always one hipGraph of 7 kernels per step)."""
         modes = {'graph': 0, 'persistent': 1}
         if mode not in modes:
