@@ -14,7 +14,7 @@ def _tokens(B, Tin, lens, seed=0):
     return tok
 
 
-@pytest.mark.parametrize('mode', ['persistent', 'graph'])
+@pytest.mark.parametrize('mode', ['persistent', 'fused', 'graph'])
 def test_encode_then_decode_equals_infer_and_can_be_repeated(gpu_engine, taco_weights, taco_cfg, mode):
     from oracle import tacotron2_ref
     gpu_engine.set_decoder_mode(mode)
@@ -40,7 +40,7 @@ def test_encode_then_decode_equals_infer_and_can_be_repeated(gpu_engine, taco_we
         with pytest.raises(ValueError, match='freed'):
             gpu_engine.tacotron2_decode(enc, max_len=4)
     finally:
-        gpu_engine.set_decoder_mode('persistent')
+        gpu_engine.set_decoder_mode('auto')
 
 
 def test_cached_decoder_graphs_survive_shape_changes(gpu_engine, taco_weights, taco_cfg):
@@ -58,7 +58,7 @@ def test_cached_decoder_graphs_survive_shape_changes(gpu_engine, taco_weights, t
             assert np.abs(out.mel - ref.mel).max() <= 1e-3, (i, B, Tin, T)
             assert np.abs(out.attention_weights - ref.attention_weights).max() <= 1e-3
     finally:
-        gpu_engine.set_decoder_mode('persistent')
+        gpu_engine.set_decoder_mode('auto')
 
 
 def test_async_calls_on_a_torch_stream_match_the_blocking_calls(gpu_engine):

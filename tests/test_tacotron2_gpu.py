@@ -31,16 +31,16 @@ def _check(out, ref, steps=None):
 MODE = 'persistent'
 
 
-@pytest.fixture(autouse=True, params=['persistent', 'graph'])
+@pytest.fixture(autouse=True, params=['persistent', 'fused', 'graph'])
 def decoder_mode(request, gpu_engine):
-    """Every test of this file runs twice: through the persistent weight-stationary decoder kernel (taken when the call
-    shape allows it: batch <= 4 and B * Tin small enough for LDS; larger shapes fall back by themselves) and through the
-    per-step hipGraph of 7 kernels."""
+    """Every test of this file runs three times: through the persistent weight-stationary decoder kernel (taken when the
+    call shape allows it: batch <= 4 and B * Tin small enough for LDS), through the fused two-kernel step (batch <= 8,
+    at most 256 tokens) -- larger shapes fall back by themselves -- and through the per-step hipGraph of 7 kernels."""
     global MODE
     MODE = request.param
     gpu_engine.set_decoder_mode(MODE)
     yield MODE
-    gpu_engine.set_decoder_mode('persistent')
+    gpu_engine.set_decoder_mode('auto')
 
 
 def _engine(weights):
@@ -53,22 +53,31 @@ def _engine(weights):
 
 
 def test_the_requested_decoder_path_is_the_one_that_runs(gpu_engine, taco_weights, taco_cfg):
-    """Guards the parametrisation above: small shapes really take the persistent kernel, and both paths agree far inside
+    """Guards the parametrisation above: small shapes really take the requested machine, and the paths agree far inside
     the mel tolerance (they differ by fp32 re-association only)."""
     tok = _tokens(2, 40, [40, 29], seed=11)
     masks = (np.random.default_rng(5).random((2, 30, 2, 256)) >= 0.5).astype(np.float32) * 2.0
     out = gpu_engine.tacotron2_infer(tok, max_len=30, early_stopping=False, prenet_masks=masks)
     assert gpu_engine.last_decoder_mode == MODE
-    gpu_engine.set_decoder_mode('graph' if MODE == 'persistent' else 'persistent')
-    other = gpu_engine.tacotron2_infer(tok, max_len=30, early_stopping=False, prenet_masks=masks)
-    assert gpu_engine.last_decoder_mode != MODE
-    d = float(np.abs(out.mel - other.mel).max())
-    print(f'persistent vs graph decoder: mel max abs diff {d:.2e}')
-    assert d <= 1e-4 and np.array_equal(out.lengths, other.lengths)
-    big = _tokens(11, 16, [16] * 11, seed=3)                          # batch 11 > 4: always the per-step graph
-    gpu_engine.set_decoder_mode('persistent')
-    gpu_engine.tacotron2_infer(big, max_len=4, early_stopping=False)
-    assert gpu_engine.last_decoder_mode == 'graph'
+    for other_mode in ('persistent', 'fused', 'graph'):
+        if other_mode == MODE:
+            continue
+        gpu_engine.set_decoder_mode(other_mode)
+        other = gpu_engine.tacotron2_infer(tok, max_len=30, early_stopping=False, prenet_masks=masks)
+        assert gpu_engine.last_decoder_mode == other_mode
+        d = float(np.abs(out.mel - other.mel).max())
+        print(f'{MODE} vs {other_mode} decoder: mel max abs diff {d:.2e}')
+        assert d <= 1e-4 and np.array_equal(out.lengths, other.lengths)
+    big = _tokens(11, 16, [16] * 11, seed=3)                          # batch 11 > 8: always the per-step graph
+    for m in ('persistent', 'fused', 'auto'):
+        gpu_engine.set_decoder_mode(m)
+        gpu_engine.tacotron2_infer(big, max_len=4, early_stopping=False)
+        assert gpu_engine.last_decoder_mode == 'graph'
+    gpu_engine.set_decoder_mode('auto')                               # the default: 1 - 2 rows persistent, 3 - 8 rows fused
+    gpu_engine.tacotron2_infer(tok, max_len=4, early_stopping=False)
+    assert gpu_engine.last_decoder_mode == 'persistent'
+    gpu_engine.tacotron2_infer(_tokens(6, 24, [24, 20, 24, 7, 24, 11], seed=4), max_len=4, early_stopping=False)
+    assert gpu_engine.last_decoder_mode == 'fused'
 
 
 def test_fixed_steps_deterministic_b1(gpu_engine, taco_weights, taco_cfg):

@@ -12,11 +12,11 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 mkdir -p "$bdir"
 objs=()
 pids=()
-for src in engine waveglow tacotron2 taco_persist mel_stft; do
+for src in engine waveglow tacotron2 taco_persist taco_fused mel_stft; do
   obj="$bdir/$src.o"
   objs+=("$obj")
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/gemm_f32.h" -nt "$obj" || "$here/engine.h" -nt "$obj" \
-        || "$here/taco_persist.h" -nt "$obj" \
+        || "$here/taco_persist.h" -nt "$obj" || "$here/xch_util.h" -nt "$obj" || "$here/taco_fused.h" -nt "$obj" \
         || "$here/../../include/tts_hip.h" -nt "$obj" ]]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$here/$src.hip" -o "$obj" &
     pids+=($!)

@@ -130,8 +130,9 @@ struct Tacotron2Dev {
     float* proj_b = nullptr;            // [81]
     float* pfold_w = nullptr;           // [256][1024 + enc]  prenet layer 1 folded with the frame projection (taco_persist.hip)
     float* pfold_b = nullptr;           // [256]
-    int persist_mode = 1;               // 1: use the persistent decoder when the call shape allows it; 0: per-step graph only
-    int last_path = -1;                 // how the last call ran its loop: 1 persistent kernel, 0 per-step graph
+    int persist_mode = 3;               // tts_hip_set_decoder_mode: 0 per-step graph only, 1 persistent kernel when allowed, 2 fused
+                                        // two-kernel step when allowed, 3 auto (persistent for 1 - 2 rows, fused above)
+    int last_path = -1;                 // how the last call ran its loop: 2 fused step, 1 persistent kernel, 0 per-step graph
     bool persist_timed = true;          // persistent kernel: timed optimistic polls on (switched off if they mostly miss)
     ConvBnDev post_conv[5];
     std::vector<void*> allocs;

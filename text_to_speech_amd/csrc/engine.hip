@@ -395,7 +395,7 @@ int tts_hip_kernel_time_us(tts_hip_engine* e, int kind, double* avg_us, int64_t*
 }
 
 int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode) {
-    if (!e || (mode != 0 && mode != 1)) return set_err(e, TTS_HIP_EINVAL, "set_decoder_mode: mode must be 0 or 1");
+    if (!e || mode < 0 || mode > 3) return set_err(e, TTS_HIP_EINVAL, "set_decoder_mode: mode must be 0 (graph), 1 (persistent), 2 (fused) or 3 (auto)");
     e->taco.persist_mode = mode;
     return TTS_HIP_OK;
 }

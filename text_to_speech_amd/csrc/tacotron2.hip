@@ -17,6 +17,7 @@
 // "stop as soon as every row has fired" semantics (:625-627) without a host round trip per step.
 #include "engine.h"
 #include "taco_persist.h"
+#include "taco_fused.h"
 
 #include <atomic>
 #include <type_traits>
@@ -1312,14 +1313,22 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
     float* d_pm = en->pm;
 
     // ---------------- workspace arena
-    const bool try_persist = persist_applicable(e, B, Tin);
-    const size_t n_xch = try_persist ? persist_xch_u64(B, Tin) : 0;
+    // Which machine runs the loop (tts_hip_set_decoder_mode): 0 = the 7-kernel per-step graph only, 1 = persistent kernel when its
+    // shape rule allows, 2 = fused two-kernel step when its shape rule allows, 3 (default) = persistent for 1 - 2 rows, fused
+    // above, whichever is applicable otherwise.  The per-step graph is the fallback of both.
+    bool try_persist = (tc.persist_mode == 1 || tc.persist_mode == 3) && persist_applicable(e, B, Tin);
+    bool try_fused = (tc.persist_mode == 2 || tc.persist_mode == 3) && !e->timing && fused_applicable(e, B, Tin);
+    if (try_persist && try_fused) {
+        if (B <= 2) try_fused = false;
+        else try_persist = false;
+    }
+    const size_t n_xch = std::max(try_persist ? persist_xch_u64(B, Tin) : (size_t)0, try_fused ? fused_xch_u64(B, Tin, enc) : (size_t)0);
     const size_t n_masks = prenet_masks ? (size_t)RB * 2 * PRE : 1;
     const size_t conv_rows = (size_t)std::min<long long>(RD, 32768);     // 512 tiles x 64 rows at most
     size_t need = 0;
     auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
     sz(n_masks, 4); sz(try_persist ? (size_t)R * PERSIST_NPM : 1, 4);
-    sz(64, 4); sz(n_xch + 2, 8); sz(16, 4);
+    sz(64, 4); sz(8, 4); sz(n_xch + 2, 8); sz(16, 4);
     sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4); sz(B * ATT, 4);
     sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
     sz(RB * NMEL, 4); sz(RB, 4); sz(RB * Tin, 4); sz(RD, 1); sz(RD * NMEL, 4); sz(RD * 512, 4); sz(RD * 512, 4);
@@ -1336,6 +1345,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
     float* d_masks = A.take<float>(n_masks);
     float* d_pmfold = A.take<float>(try_persist ? (size_t)R * PERSIST_NPM : 1);
     DecState* d_state = A.take<DecState>(1);
+    FusedState* d_fstate = A.take<FusedState>(1);
     unsigned long long* d_xch = A.take<unsigned long long>(n_xch + 2);
     int* d_pflags = A.take<int>(16);
     float* d_hatt = A.take<float>(2 * B * ARNN);
@@ -1464,7 +1474,44 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         return TTS_HIP_OK;
     };
     int host_steps = 0;
-    bool persisted = false;
+    bool persisted = false, fused = false;
+    // the workspace layout (and with it every pointer a captured graph holds) depends on which exchange areas were sized in
+    const int layout_id = (try_persist ? 1 : 0) | (try_fused ? 2 : 0);
+    // instantiated chunk graphs are kept and replayed by every later call with the same shape bucket: the workspace and the
+    // encoded batch are stable allocations, so the kernel nodes hold valid pointers
+    auto cached_graph = [&](const DecGraphKey& key, auto&& enqueue, hipGraphExec_t* out) -> int {
+        auto it = tc.graphs.find(key);
+        if (it != tc.graphs.end()) {
+            *out = it->second;
+            return TTS_HIP_OK;
+        }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int crc = enqueue();
+        hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (crc != TTS_HIP_OK || ce != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            if (crc != TTS_HIP_OK) return crc;
+            HIPCHK(e, ce);
+        }
+        hipError_t ie = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);             // the executable graph is self-contained
+        HIPCHK(e, ie);
+        constexpr size_t kMaxGraphs = 16;
+        if (tc.graph_order.size() >= kMaxGraphs) {
+            auto old = tc.graphs.find(tc.graph_order.front());
+            if (old != tc.graphs.end()) {
+                (void)hipGraphExecDestroy(old->second);
+                tc.graphs.erase(old);
+            }
+            tc.graph_order.erase(tc.graph_order.begin());
+        }
+        tc.graphs[key] = gexec;
+        tc.graph_order.push_back(key);
+        *out = gexec;
+        return TTS_HIP_OK;
+    };
     int bl_err = 0;
     bool bl_checked = false;
     if (try_persist) {
@@ -1505,8 +1552,82 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
             HIPCHK(e, hipGetLastError());
         }
     }
-    tc.last_path = persisted ? 1 : 0;
-    if (!persisted) {
+    if (try_fused) {
+        // Fused two-kernel step (taco_fused.hip): chunks of FUSED_CHUNK steps, one hipGraph per shape bucket; after each chunk
+        // the host reads the loop state (32 bytes) and the abort flag.
+        FusedCall fc{};
+        fc.B = B; fc.Tin = Tin; fc.max_len = max_len; fc.early_stop = early_stop ? 1 : 0;
+        fc.win_len = win_len; fc.win_off = win_offset; fc.half_w = half_w;
+        fc.memory = d_memory; fc.pm = d_pm; fc.mask = d_mask; fc.enc_len = d_enc_len; fc.masks = masks_dev;
+        fc.xch = d_xch; fc.flags = d_pflags; fc.state = d_fstate;
+        fc.hatt = d_hatt; fc.hdec = d_hdec; fc.catt = d_catt; fc.cdec = d_cdec; fc.ctx = d_ctx;
+        fc.wprev = d_wprev; fc.wcum = d_wcum; fc.mainatt = d_mainatt;
+        fc.dec_out = d_decout; fc.stop_out = d_stop; fc.attn_hist = d_attn; fc.lengths = d_lengths; fc.finished = d_finished;
+        if ((rc = fused_init(e, st, fc))) return rc;
+        hipGraphExec_t gexec = nullptr;
+#ifdef TTS_DEBUG_HOOKS
+        const bool fgraph = getenv("TTS_HIP_NO_GRAPH") == nullptr;
+        const char* trace_file = getenv("TTS_FUSED_TRACE_FILE");       // phase timestamps of the first 128 steps (scripts/fused_trace.py)
+        const size_t trace_n = (size_t)128 * 2 * 4 * 16;
+        if (trace_file) {
+            HIPCHK(e, hipMalloc((void**)&fc.trace, trace_n * sizeof(long long)));
+            HIPCHK(e, hipMemsetAsync(fc.trace, 0, trace_n * sizeof(long long), st));
+            hipGraph_t graph = nullptr;                                 // a graph of its own: the trace pointer is baked in
+            HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int crc = fused_enqueue_chunk(e, st, fc);
+            HIPCHK(e, hipStreamEndCapture(st, &graph));
+            if (crc) return crc;
+            HIPCHK(e, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+        }
+#else
+        constexpr bool fgraph = true;
+        constexpr const char* trace_file = nullptr;
+#endif
+        if (fgraph && !trace_file) {
+            const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, prenet_masks ? 1 : 0, win_len, win_offset,
+                                  half_w ? 1 : 0, layout_id | 4};
+            if ((rc = cached_graph(key, [&]() { return fused_enqueue_chunk(e, st, fc); }, &gexec))) return rc;
+        }
+        FusedState h{};
+        int abort_code = 0;
+        fused = true;
+        for (int t0 = 0; t0 < max_len; t0 += FUSED_CHUNK) {
+            if (fgraph) HIPCHK(e, hipGraphLaunch(gexec, st));
+            else if ((rc = fused_enqueue_chunk(e, st, fc))) return rc;
+            HIPCHK(e, hipMemcpyAsync(&h, d_fstate, sizeof h, hipMemcpyDeviceToHost, st));
+            HIPCHK(e, hipMemcpyAsync(&abort_code, d_pflags, sizeof abort_code, hipMemcpyDeviceToHost, st));
+            if (t0 == 0) HIPCHK(e, hipMemcpyAsync(&bl_err, en->bl_err, sizeof bl_err, hipMemcpyDeviceToHost, st));
+            HIPCHK(e, hipStreamSynchronize(st));
+            bl_checked = true;
+            if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
+            if (abort_code != 0) {                      // an exchange timed out (e.g. the GPU was shared and a block lost its CU):
+                fused = false;                          // start over on the per-step graph
+                set_err(e, TTS_HIP_EHIP, "tacotron2 fused decoder: exchange timed out (code %d); fell back to the per-step graph", abort_code);
+                if ((rc = zero_state())) return rc;
+                hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
+                HIPCHK(e, hipGetLastError());
+                break;
+            }
+            host_steps = h.steps_run;
+            if (h.steps_run < std::min(t0 + FUSED_CHUNK, max_len)) break;      // the loop ended inside this chunk
+            if (early_stop && h.n_fin >= B) break;     // ... or with the stop tokens of its last step
+        }
+#ifdef TTS_DEBUG_HOOKS
+        if (fc.trace) {
+            std::vector<long long> ht(trace_n);
+            (void)hipMemcpy(ht.data(), fc.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost);
+            (void)hipFree(fc.trace);
+            (void)hipGraphExecDestroy(gexec);
+            if (FILE* f = fopen(trace_file, "wb")) {
+                fwrite(ht.data(), sizeof(long long), trace_n, f);
+                fclose(f);
+            }
+        }
+#endif
+    }
+    tc.last_path = persisted ? 1 : fused ? 2 : 0;
+    if (!persisted && !fused) {
         // chunks of CHUNK steps; after each chunk the host reads the loop state (one 32-byte copy)
         DecState h{};
 #ifdef TTS_DEBUG_HOOKS
@@ -1516,40 +1637,15 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
 #endif
         hipGraphExec_t gexec = nullptr;
         if (use_graph) {
-            // The instantiated graph of a chunk is kept and replayed by every later call with the same shape bucket: the
-            // workspace and the encoded batch are stable allocations, so the 225 kernel nodes hold valid pointers.
             const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, prenet_masks ? 1 : 0, win_len, win_offset,
-                                  half_w ? 1 : 0, try_persist ? 1 : 0};
-            auto it = tc.graphs.find(key);
-            if (it != tc.graphs.end()) {
-                gexec = it->second;
-            } else {
-                hipGraph_t graph = nullptr;
-                HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                                  half_w ? 1 : 0, layout_id};
+            auto enqueue = [&]() -> int {
                 int crc = TTS_HIP_OK;
                 for (int j = 0; j < CHUNK && crc == TTS_HIP_OK; ++j) crc = enqueue_step(j);
                 if (crc == TTS_HIP_OK) hipLaunchKernelGGL(advance_chunk_kernel, dim3(1), dim3(1), 0, st, d_state);
-                hipError_t ce = hipStreamEndCapture(st, &graph);
-                if (crc != TTS_HIP_OK || ce != hipSuccess) {
-                    if (graph) (void)hipGraphDestroy(graph);
-                    if (crc != TTS_HIP_OK) return crc;
-                    HIPCHK(e, ce);
-                }
-                hipError_t ie = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);             // the executable graph is self-contained
-                HIPCHK(e, ie);
-                constexpr size_t kMaxGraphs = 16;
-                if (tc.graph_order.size() >= kMaxGraphs) {
-                    auto old = tc.graphs.find(tc.graph_order.front());
-                    if (old != tc.graphs.end()) {
-                        (void)hipGraphExecDestroy(old->second);
-                        tc.graphs.erase(old);
-                    }
-                    tc.graph_order.erase(tc.graph_order.begin());
-                }
-                tc.graphs[key] = gexec;
-                tc.graph_order.push_back(key);
-            }
+                return crc;
+            };
+            if ((rc = cached_graph(key, enqueue, &gexec))) return rc;
         }
         for (int t0 = 0; t0 < max_len; t0 += CHUNK) {
             if (use_graph) {

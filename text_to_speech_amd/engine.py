@@ -299,17 +299,18 @@ class HipEngine:
                                         lengths=lengths)
 
     def set_decoder_mode(self, mode: str) -> None:
-        """'persistent' (default: one weight-stationary persistent kernel for the whole decoder loop when the call shape
-        allows it) or 'graph' (always one hipGraph of 7 kernels per step)."""
-        modes = {'graph': 0, 'persistent': 1}
+        """How the autoregressive decoder loop runs: 'auto' (default: the persistent weight-stationary kernel for 1 - 2 rows,
+        the fused two-kernel step for 3 - 8 rows, whichever applies otherwise), 'persistent' / 'fused' (that machine when the
+        call shape allows it) or 'graph' (always one hipGraph of 7 kernels per step, the fallback of the other two)."""
+        modes = {'graph': 0, 'persistent': 1, 'fused': 2, 'auto': 3}
         if mode not in modes:
             raise ValueError(f'mode must be one of {tuple(modes)}, got {mode!r}')
         self._check(self._lib.tts_hip_set_decoder_mode(self._h, modes[mode]), 'set_decoder_mode')
 
     @property
     def last_decoder_mode(self) -> str:
-        """How the last `tacotron2_infer` call ran its loop: 'persistent', 'graph', or 'none' before the first call."""
-        return {1: 'persistent', 0: 'graph'}.get(self._lib.tts_hip_last_decoder_mode(self._h), 'none')
+        """How the last `tacotron2_infer` call ran its loop: 'fused', 'persistent', 'graph', or 'none' before the first call."""
+        return {2: 'fused', 1: 'persistent', 0: 'graph'}.get(self._lib.tts_hip_last_decoder_mode(self._h), 'none')
 
     # ------------------------------------------------------------------ mel-STFT
     def mel_stft(self, audio, stream=None):
