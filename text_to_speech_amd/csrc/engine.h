@@ -141,6 +141,8 @@ struct Tacotron2Dev {
     tts_hip_encoded* enc_cache = nullptr;                 // encoder output of tts_hip_tacotron2_infer* calls (reused: stable pointers)
     std::map<DecGraphKey, hipGraphExec_t> graphs;         // instantiated decoder-chunk graphs, replayed across calls
     std::vector<DecGraphKey> graph_order;                 // insertion order (oldest evicted first)
+    void* pinned = nullptr;                               // pinned host ring for the decoder loop's chunk reports (2 x 64 bytes)
+    hipEvent_t chunk_ev[2] = {nullptr, nullptr};
 };
 
 struct MelStftDev {

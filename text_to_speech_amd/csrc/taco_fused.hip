@@ -108,23 +108,30 @@ constexpr int FTR_STEPS = 128, FTR_SLOTS = 16;
 #define FTR(kind, slot) do { } while (0)
 #endif
 
+// LDS words that waves of a block signal each other through.  An explicit LDS pointer type: through a generic `volatile int*`
+// the compiler emits flat_load / flat_store + s_waitcnt vmcnt(0), i.e. every look at such a word also waited for the wave's
+// outstanding global stores (a publish costs ~1 us to be acknowledged under the weight stream).
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ int lds_peek(const lds_int* p) { return *(const volatile lds_int*)p; }
+__device__ __forceinline__ void lds_poke(lds_int* p, int v) { *(volatile lds_int*)p = v; }
+
 // ---------------------------------------------------------------------------------------------------- wave-level polls
 struct WavePoll {
     __amdgpu_buffer_rsrc_t rs;            // the whole exchange area
     int* flags;                           // global: [0] abort code
-    int* abort_s;                         // LDS: set by any wave of the block that gave up
+    lds_int* abort_s;                     // LDS: set by any wave of the block that gave up
 
     __device__ __forceinline__ bool should_stop(long long spins) const {
-        if ((spins & 63) == 0 && *(volatile int*)abort_s) return true;
+        if ((spins & 63) == 0 && lds_peek(abort_s)) return true;
         if ((spins & 1023) == 0 && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            *(volatile int*)abort_s = 1;
+            lds_poke(abort_s, 1);
             return true;
         }
         return false;
     }
     __device__ __forceinline__ void give_up() const {
         __hip_atomic_store(flags, ABORT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *(volatile int*)abort_s = 1;
+        lds_poke(abort_s, 1);
     }
     // One pair, the same address in every lane (a single 16-byte request per poll), sleeping between polls.
     __device__ __forceinline__ u32x4 wait_pair(unsigned entry, unsigned tag) const {
@@ -312,21 +319,35 @@ __device__ __forceinline__ void load_slice(WSlice<HW>& w, const void* base, long
     for (int g = 0; g < 4; ++g) w.g[g] = load_w<HW, NT>(base, (row0 + g) * K + koff + lane * 4);
 }
 
+// Every block stages the same rows at the same moment: starting each block at its own offset keeps the 32 CUs of an XCD from
+// walking the L2 channels in lock step.  (TTS_FUSED_ROT=0: all blocks in the same order.)
+#ifndef TTS_FUSED_ROT
+#define TTS_FUSED_ROT 0
+#endif
+__device__ __forceinline__ int stage_index(int idx, int blk, int total) {
+#if TTS_FUSED_ROT
+    const int r = idx + ((blk >> 3) * 160) % total;      // blocks b, b + 8, ... share an XCD: 32 different offsets, 2.5 KiB apart
+    return r >= total ? r - total : r;
+#else
+    return idx;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------- timed polls
 // The 256 blocks run in lock step (entry within ~0.3 us), and every block holds a producer of every hop.  So a consumer
 // does not watch the exchange area while it waits: it spins on an LDS word in which the block's own producer leaves the
 // (100 MHz) time of its publish, sleeps until that time + the hop's latency, and only then loads its pairs -- usually once.
 // Tags decide, time only chooses when to look.  Hops: 0 p1, 1 p2, 2 q, 3 energies, 4 context.
 constexpr long long LDS_SPIN_LIMIT = 1 << 22;
-__device__ __forceinline__ void stamp(int* ts) {
-    *(volatile int*)ts = (int)((unsigned)wall_clock64() | 1u);
+__device__ __forceinline__ void stamp(lds_int* ts) {
+    lds_poke(ts, (int)((unsigned)wall_clock64() | 1u));
 }
-__device__ __forceinline__ void wait_stamp(const WavePoll& P, const int* ts, int delay) {
+__device__ __forceinline__ void wait_stamp(const WavePoll& P, const lds_int* ts, int delay) {
     long long spins = 0;
     int v;
-    while ((v = *(volatile const int*)ts) == 0) {
+    while ((v = lds_peek(ts)) == 0) {
         if (++spins > LDS_SPIN_LIMIT) { P.give_up(); return; }
-        if ((spins & 255) == 0 && *(volatile int*)P.abort_s) return;
+        if ((spins & 255) == 0 && lds_peek(P.abort_s)) return;
         __builtin_amdgcn_s_sleep(1);
     }
     while ((int)((unsigned)wall_clock64() - (unsigned)(v + delay)) < 0) __builtin_amdgcn_s_sleep(1);
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                                  // [NBT][KX]
     float* p2s = xs + NBT * KX;                       // [NBT][256]
-    int* ctl = (int*)(p2s + NBT * PRE);               // [0] abort, [1] finished count, [2..4] publish times: p1 (two waves), p2
+    lds_int* ctl = (lds_int*)(p2s + NBT * PRE);       // [0] abort, [1] finished count, [2..4] publish times: p1 (two waves), p2
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
     const FusedState s = *a.st;
@@ -390,7 +411,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
         const float* hd = a.hdec + (size_t)par * B * RNN;
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            const int idx = tid + i * NTHR;
+            const int idx = stage_index(tid + i * NTHR, blk, NST * NTHR);
             const int b = idx / (KX / 4), k = (idx - b * (KX / 4)) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (idx < NBT * KX / 4 && b < B) {
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
     auto store_staged = [&]() {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            const int idx = tid + i * NTHR;
+            const int idx = stage_index(tid + i * NTHR, blk, NST * NTHR);
             if (idx < NBT * KX / 4) *reinterpret_cast<f32x4*>(xs + (size_t)idx * 4) = sv[i];
         }
         for (int i = tid; i < NBT * PRE; i += NTHR) p2s[i] = 0.f;
@@ -449,6 +470,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
             if (e + PF < NE) load_slice<HW, !HW>(w, a.Wa, row0, KA, ekoff(e + PF), lane);
             else if (e + PF == NE) load_slice<HW, !HW>(wl, a.Wa, row0, KA, 0, lane);       // the p2 slice last: it waits for the chain
             asm volatile("" ::: "memory");
+            if (e == 0 && wave == 0) FTR(0, 13);
         }
         if (wave == 0) FTR(0, 10);
         __syncthreads();                              // #2: p2 and the finished count are in LDS
@@ -530,6 +552,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
     if (is_p1) {                                      // prenet layer 1 folded with the projection; go frame at t = 0
         float sm[HB];
         role_dots<HB, NP>(sm, R, xs + (size_t)row_lo * KX, KX, pcol, lane);
+        if (r == 0) FTR(0, 15);
         if (lane < HB && row_lo + lane < B) {
             float v = pick_row<HB>(sm, lane) + rbias;
             v = t == 0 ? 0.f : fmaxf(v, 0.f) * dmask;
@@ -604,7 +627,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     float* wl = xs + NBT * KX;                        // [62][128]
     float* wsm = wl + 2 * LOCK * ATT;                 // [4 role waves][TP] softmax weights
     float* msl = wsm + 4 * TP;                        // [4 role waves][TP][8] encoder outputs: 8 columns of one row
-    int* ctl = (int*)(msl + 4 * TP * 8);              // [0] abort, [2..4] publish times: q, energies, context
+    lds_int* ctl = (lds_int*)(msl + 4 * TP * 8);      // [0] abort, [2..4] publish times: q, energies, context
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
     const FusedState s = *a.st;
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
         const float* hd = a.hdec + (size_t)par * B * RNN;
 #pragma unroll
         for (int i = 0; i < NSH; ++i) {
-            const int idx = tid + i * NTHR;           // float4 index in [NBT][2048]
+            const int idx = stage_index(tid + i * NTHR, blk, NSH * NTHR);      // float4 index in [NBT][2048]
             const int b = idx / 512, k = (idx % 512) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (b < B) v = *reinterpret_cast<const f32x4*>(k < RNN ? ha + (size_t)b * RNN + k : hd + (size_t)b * RNN + (k - RNN));
@@ -641,7 +664,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     auto store_staged = [&]() {
 #pragma unroll
         for (int i = 0; i < NSH; ++i) {
-            const int idx = tid + i * NTHR;
+            const int idx = stage_index(tid + i * NTHR, blk, NSH * NTHR);
             const int b = idx / 512, k = (idx % 512) * 4;
             *reinterpret_cast<f32x4*>(xs + (size_t)b * KX + (k < RNN ? k : k + ENC)) = sv[i];
         }
@@ -777,6 +800,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
         float sm[HB];
         const int qcol[4] = {0, 256, 512, 768};
         role_dots<HB, 4>(sm, RQ, xs + (size_t)qrow * KX, KX, qcol, lane);
+        FTR(1, 15);
         if (lane < HB && qrow + lane < B) publish(a.xch + X.q + (qrow + lane) * ATT + qdim, tag, pick_row<HB>(sm, lane));
         if (lane == 0) stamp(ctl + 2);
         FTR(1, 3);

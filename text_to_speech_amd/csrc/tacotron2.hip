@@ -972,6 +972,14 @@ void tacotron2_free(tts_hip_engine* e) {
     e->taco.pfold_w = nullptr;
     e->taco.pfold_b = nullptr;
     tacotron2_graphs_clear(e);
+    if (e->taco.pinned) {
+        (void)hipHostFree(e->taco.pinned);
+        e->taco.pinned = nullptr;
+        for (auto& ev : e->taco.chunk_ev) {
+            if (ev) (void)hipEventDestroy(ev);
+            ev = nullptr;
+        }
+    }
     if (e->taco.enc_cache) {
         e->taco.enc_cache->buf.release();
         delete e->taco.enc_cache;
@@ -1589,29 +1597,57 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
                                   half_w ? 1 : 0, layout_id | 4};
             if ((rc = cached_graph(key, [&]() { return fused_enqueue_chunk(e, st, fc); }, &gexec))) return rc;
         }
-        FusedState h{};
-        int abort_code = 0;
+        // Chunk k + 1 is enqueued BEFORE the host looks at chunk k's loop state, so the GPU never waits for the host between
+        // chunks (a sync + relaunch per 32 steps cost ~1.2 us per step); the state travels through a pinned ring.  When chunk k
+        // turns out to have ended the loop, chunk k + 1 is 66 kernels that return at once (~0.1 ms, once per call).
+        struct ChunkReport { FusedState st; int abort_code; int bl_err; int pad[6]; };
+        static_assert(sizeof(ChunkReport) == 64, "one report per 64-byte slot");
+        if (!tc.pinned) {
+            HIPCHK(e, hipHostMalloc(&tc.pinned, 2 * sizeof(ChunkReport), hipHostMallocDefault));
+            for (auto& ev : tc.chunk_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        ChunkReport* rep = (ChunkReport*)tc.pinned;
         fused = true;
-        for (int t0 = 0; t0 < max_len; t0 += FUSED_CHUNK) {
+        const int n_chunks = (max_len + FUSED_CHUNK - 1) / FUSED_CHUNK;
+        auto enqueue = [&](int k) -> int {
             if (fgraph) HIPCHK(e, hipGraphLaunch(gexec, st));
-            else if ((rc = fused_enqueue_chunk(e, st, fc))) return rc;
-            HIPCHK(e, hipMemcpyAsync(&h, d_fstate, sizeof h, hipMemcpyDeviceToHost, st));
-            HIPCHK(e, hipMemcpyAsync(&abort_code, d_pflags, sizeof abort_code, hipMemcpyDeviceToHost, st));
-            if (t0 == 0) HIPCHK(e, hipMemcpyAsync(&bl_err, en->bl_err, sizeof bl_err, hipMemcpyDeviceToHost, st));
-            HIPCHK(e, hipStreamSynchronize(st));
+            else if (int rc2 = fused_enqueue_chunk(e, st, fc)) return rc2;
+            ChunkReport* r = rep + (k & 1);
+            HIPCHK(e, hipMemcpyAsync(&r->st, d_fstate, sizeof(FusedState), hipMemcpyDeviceToHost, st));
+            HIPCHK(e, hipMemcpyAsync(&r->abort_code, d_pflags, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(e, hipMemcpyAsync(&r->bl_err, en->bl_err, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(e, hipEventRecord(tc.chunk_ev[k & 1], st));
+            return TTS_HIP_OK;
+        };
+        if ((rc = enqueue(0))) return rc;
+        for (int k = 0; k < n_chunks; ++k) {
+            if (k + 1 < n_chunks && (rc = enqueue(k + 1))) return rc;
+            HIPCHK(e, hipEventSynchronize(tc.chunk_ev[k & 1]));
+            const ChunkReport h = rep[k & 1];
             bl_checked = true;
-            if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
-            if (abort_code != 0) {                      // an exchange timed out (e.g. the GPU was shared and a block lost its CU):
+            bl_err = h.bl_err;
+            bool stop = false;
+            if (bl_err) {
+                stop = true;
+            } else if (h.abort_code != 0) {             // an exchange timed out (e.g. the GPU was shared and a block lost its CU):
                 fused = false;                          // start over on the per-step graph
-                set_err(e, TTS_HIP_EHIP, "tacotron2 fused decoder: exchange timed out (code %d); fell back to the per-step graph", abort_code);
-                if ((rc = zero_state())) return rc;
-                hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
-                HIPCHK(e, hipGetLastError());
+                stop = true;
+            } else {
+                host_steps = h.st.steps_run;
+                if (h.st.steps_run < std::min((k + 1) * FUSED_CHUNK, max_len)) stop = true;      // the loop ended inside this chunk
+                if (early_stop && h.st.n_fin >= B) stop = true;                                  // ... or with the stop tokens of its last step
+            }
+            if (stop) {
+                if (k + 1 < n_chunks) HIPCHK(e, hipEventSynchronize(tc.chunk_ev[(k + 1) & 1]));     // the chunk already in flight (it does nothing)
                 break;
             }
-            host_steps = h.steps_run;
-            if (h.steps_run < std::min(t0 + FUSED_CHUNK, max_len)) break;      // the loop ended inside this chunk
-            if (early_stop && h.n_fin >= B) break;     // ... or with the stop tokens of its last step
+        }
+        if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
+        if (!fused) {
+            set_err(e, TTS_HIP_EHIP, "tacotron2 fused decoder: an exchange timed out; fell back to the per-step graph");
+            if ((rc = zero_state())) return rc;
+            hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
+            HIPCHK(e, hipGetLastError());
         }
 #ifdef TTS_DEBUG_HOOKS
         if (fc.trace) {
