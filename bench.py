@@ -212,24 +212,23 @@ def secondary_metrics(eng, dev, rank):
     del mel8, z8
     eng.load_state(weights.synth_tacotron2(Tacotron2Config(), seed=1234))
     eng.finalize()
-    # Two ways to run the loop: 'persistent' = one weight-stationary cooperative kernel for the whole
-    # utterance (batch <= 4: no weight streaming at all, the step is bound by six CU-to-CU exchange hops), 'graph' = 7 kernels
-    # per step in a hipGraph, every LSTM weight streamed from HBM every step (the only path above batch 4).  The default
-    # ('persistent', falling back by itself) is what the plain keys report; `_graph` keys time the other path.
+    # Three ways to run the loop: 'persistent' = one weight-stationary kernel for the whole utterance
+    # (no weight streaming at all, the step is bound by six CU-to-CU exchange hops; taken for 1 - 2 rows), 'fused' = two kernels
+    # per step with in-kernel exchanges, every LSTM weight streamed once per step beside the dependency chain (3 - 8 rows),
+    # 'graph' = 7 kernels per step in a hipGraph (any shape; the fallback).  The default ('auto') is what the plain keys
+    # report; `_graph` keys time the 7-kernel path.
     for B in (1, 2, 4, 8):
         tok = np.zeros((B, 128), np.int32)
         tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
         tok_d = torch.from_numpy(tok).to(dev)
-        for mode in ('persistent', 'graph'):
+        for mode in ('auto', 'graph'):
             eng.set_decoder_mode(mode)
             for prec, tag, nbytes in (('f32', '', DECODER_STEP_BYTES_F32), ('f16', '_f16w', DECODER_STEP_BYTES_F16W)):
                 if B in (2, 4) and prec == 'f16':
                     continue
                 eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False, precision=prec)
                 ran = eng.last_decoder_mode
-                if mode == 'graph' and B == 8:
-                    continue                              # batch 8 already ran on the graph path under 'persistent'
-                key = f'tacotron2_batch{B}{tag}' + ('' if mode == 'persistent' else '_graph')
+                key = f'tacotron2_batch{B}{tag}' + ('' if mode == 'auto' else '_graph')
                 # the call's fixed part (encoder, postnet, transfers) is separated from the per-step cost with two lengths
                 reps = 3
                 times = {}
@@ -244,14 +243,14 @@ def secondary_metrics(eng, dev, rank):
                 out[f'{key}_us_per_decoder_step'] = 1e6 * dt / FRAMES          # whole call / steps
                 out[f'{key}_us_per_decoder_step_marginal'] = step_us            # loop only
                 out[f'{key}_decoder_path'] = ran
-                if ran == 'graph':
+                if ran in ('graph', 'fused'):
                     # streaming roofline: all step weights once per step from HBM
                     out[f'{key}_decoder_hbm_frac'] = nbytes / (step_us * 1e-6) / (HBM_PEAK_TBS * 1e12)
                 else:
                     # weight-stationary: nothing is streamed; the bound is the exchange chain (6 hops x ~1.2 us measured
                     # floor of one tagged CU-to-CU hop, scripts/micro/xcd_exchange.cpp)
                     out[f'{key}_exchange_floor_frac'] = 6 * 1.2 / step_us
-    eng.set_decoder_mode('persistent')
+    eng.set_decoder_mode('auto')
     # BASELINE.json configs[2] shape: full text -> audio pipeline, batch 8, mixed token counts 50..200 padded to 256,
     # mel kept on the GPU between the two models, fp16 modes of both models (decoder LSTM weights fp16; WaveGlow GEMM
     # operands fp16; fp32 accumulation everywhere).

@@ -382,52 +382,73 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
     constexpr int KA = PRE + ENC + RNN;               // attention-LSTM row: [p2 | ctx | h_att]
     constexpr int KP = RNN + ENC, NP = KP / 256;      // projection / folded prenet rows: [h_dec | ctx]
     constexpr int V = 4 * NBT, HB = NBT / 2;
-    constexpr int NST = (NBT * KX / 4 + NTHR - 1) / NTHR;   // staging float4 per thread
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                                  // [NBT][KX]
     float* p2s = xs + NBT * KX;                       // [NBT][256]
     lds_int* ctl = (lds_int*)(p2s + NBT * PRE);       // [0] abort, [1] finished count, [2..4] publish times: p1 (two waves), p2
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    const int B = a.B;
+    const int par = j & 1;                            // = t & 1 (chunks are even): h(t - 1) lives in buffer t & 1, h(t) goes to the other one
+    // Everything requested before the loop state is looked at: the state is the third load of a dependent chain (kernel
+    // arguments -> state -> ...), and waiting for it first put ~1 us of latency in front of the staging loads.  A kernel that
+    // turns out to have nothing to do returns with these loads outstanding.
+    // ---- staging in two stages.  Every thread: its share of [ctx(t-1) | h_dec(t-1)] of rows < B -> LDS (zeros beyond B) in
+    // front of barrier #1: that is what the chain (prenet 1, projection) and the first weight slices need.  h_att(t-1) is only
+    // read by the LSTM waves' later slices: they fetch it themselves and meet on an LDS counter (ctl[5]), off the chain's path.
+    constexpr int RW = (ENC + RNN) / 4;               // float4 per row of the first stage
+    constexpr int NS1 = (NBT * RW + NTHR - 1) / NTHR;
+    constexpr int NS2 = NBT * (RNN / 4) / 256;        // h_att float4 per LSTM thread
+    f32x4 sv[NS1];
+    {
+        const float* hd = a.hdec + (size_t)par * B * RNN;
+#pragma unroll
+        for (int i = 0; i < NS1; ++i) {
+            const int idx = tid + i * NTHR;
+            const int b = idx / RW, k = (idx - b * RW) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < NBT * RW && b < B) v = *reinterpret_cast<const f32x4*>(k < ENC ? a.ctx + (size_t)b * ENC + k : hd + (size_t)b * RNN + (k - ENC));
+            sv[i] = v;
+        }
+    }
+    constexpr int NC_ = ENC / 256;
+    auto ekoff = [](int e) { return e < NC_ ? PRE + e * 256 : PRE + ENC + (e - NC_) * 256; };      // column inside the weight row
+    f32x4 hv[NS2];                                    // LSTM waves: this thread's share of h_att(t-1)
+    WSlice<HW> win[PF];
+    if (wave < 4) {
+        const float* ha = a.hatt + (size_t)par * B * RNN;
+#pragma unroll
+        for (int i = 0; i < NS2; ++i) {
+            const int idx = tid + i * 256;
+            const int b = idx / (RNN / 4), k = (idx % (RNN / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) v = *reinterpret_cast<const f32x4*>(ha + (size_t)b * RNN + k);
+            hv[i] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < PRE_SL; ++e) load_slice<HW, !HW>(win[e], a.Wa, 4ll * (blk * 4 + wave), KA, ekoff(e), lane);
+    }
+    asm volatile("" ::: "memory");
     const FusedState s = *a.st;
     const int t = s.t0 + j;
     if (s.steps_run != t) return;                     // the loop ended before this step
-    if (*(volatile const int*)a.flags != 0) return;   // an earlier kernel gave up
+    if (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;       // an earlier kernel gave up
     const bool frame_on = t >= 1 && (j >= 1 || tail != 0);       // frame / stop token of step t - 1 (j == 0: the previous chunk's tail did it)
     const bool step_on = tail == 0 && t < s.max_len;
     if (!frame_on && !step_on) return;
-    const int B = a.B, max_len = s.max_len;
+    const int max_len = s.max_len;
     const unsigned tag = (unsigned)t + 1;
-    const int par = t & 1;                            // h(t - 1) lives in buffer t & 1, h(t) goes to the other one
     const FX X = fx_layout(B, a.Tin, ENC);
     if (wave == 0) FTR(0, 8);
     if (wave == 4) FTR(0, 0);
 
-    // ---- every thread: its share of [h_att(t-1) | ctx(t-1) | h_dec(t-1)] of rows < B -> LDS (zeros beyond B).  All loads
-    // are requested before anything else; the role operands and the first weight slices follow them in the queue.
-    f32x4 sv[NST];
-    {
-        const float* ha = a.hatt + (size_t)par * B * RNN;
-        const float* hd = a.hdec + (size_t)par * B * RNN;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int idx = stage_index(tid + i * NTHR, blk, NST * NTHR);
-            const int b = idx / (KX / 4), k = (idx - b * (KX / 4)) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < NBT * KX / 4 && b < B) {
-                const float* src = k < RNN ? ha + (size_t)b * RNN + k
-                                 : k < RNN + ENC ? a.ctx + (size_t)b * ENC + (k - RNN)
-                                                 : hd + (size_t)b * RNN + (k - RNN - ENC);
-                v = *reinterpret_cast<const f32x4*>(src);
-            }
-            sv[i] = v;
-        }
-    }
+
     auto store_staged = [&]() {
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int idx = stage_index(tid + i * NTHR, blk, NST * NTHR);
-            if (idx < NBT * KX / 4) *reinterpret_cast<f32x4*>(xs + (size_t)idx * 4) = sv[i];
+        for (int i = 0; i < NS1; ++i) {
+            const int idx = tid + i * NTHR;
+            const int b = idx / RW, k = (idx - b * RW) * 4;
+            if (idx < NBT * RW) *reinterpret_cast<f32x4*>(xs + (size_t)b * KX + RNN + k) = sv[i];
         }
         for (int i = tid; i < NBT * PRE; i += NTHR) p2s[i] = 0.f;
         if (tid < 8) ctl[tid] = tid == 1 ? s.n_fin : 0;
@@ -445,17 +466,20 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
             return;
         }
         const long long row0 = 4ll * u;
-        auto ekoff = [](int e) { return e < NC ? PRE + e * 256 : PRE + ENC + (e - NC) * 256; };      // column inside the weight row
         auto excol = [](int e) { return e < NC ? RNN + e * 256 : (e - NC) * 256; };                 // column inside the LDS row
-        WSlice<HW> wl, win[PF];
-#pragma unroll
-        for (int e = 0; e < PRE_SL; ++e) load_slice<HW, !HW>(win[e], a.Wa, row0, KA, ekoff(e), lane);
+        WSlice<HW> wl;
         const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.ba + 4 * u);
         const float c_old = lane < B ? a.catt[(size_t)lane * RNN + u] : 0.f;
         asm volatile("" ::: "memory");
         store_staged();
-        __syncthreads();                              // #1: x staged
+        __syncthreads();                              // #1: ctx, h_dec staged
         if (wave == 0) FTR(0, 9);
+#pragma unroll
+        for (int i = 0; i < NS2; ++i) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<f32x4*>(xs + (size_t)(idx / (RNN / 4)) * KX + (idx % (RNN / 4)) * 4) = hv[i];
+        }
+        if (lane == 0) __hip_atomic_fetch_add(ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int e = PRE_SL; e < PF; ++e) load_slice<HW, !HW>(win[e], a.Wa, row0, KA, ekoff(e), lane);
         asm volatile("" ::: "memory");
@@ -465,6 +489,10 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             WSlice<HW>& w = win[e % PF];
+            if (e == NC) {                            // first h_att slice: every LSTM wave has stored its share
+                long long spins = 0;
+                while (lds_peek(ctl + 5) < 4 && ++spins < LDS_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+            }
             fma_slice<NBT>(acc, w.g[0], w.g[1], w.g[2], w.g[3], xs + excol(e), KX, lane);
             asm volatile("" ::: "memory");            // the refill is requested here, not hoisted to the top
             if (e + PF < NE) load_slice<HW, !HW>(w, a.Wa, row0, KA, ekoff(e + PF), lane);
@@ -620,8 +648,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     constexpr int NPOS = (NBT * TP + 1023) / 1024;    // (row, position) pairs a role wave may own
     constexpr int MPF = 16 * KT;                      // positions per lane of a context unit (8 time slices x 8 columns per wave)
     constexpr int CU_PER_ROW = ENC / 8;
-    constexpr int NSH = NBT * 2 * RNN / 4 / NTHR;     // staging float4 per thread: hidden states
-    constexpr int NL4 = 2 * LOCK * ATT / 4, NSL = (NL4 + NTHR - 1) / NTHR;       // ... location map
+    constexpr int NL4 = 2 * LOCK * ATT / 4, NSL = (NL4 + 255) / 256;             // location map: float4 per role thread
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                                  // [NBT][KX]
     float* wl = xs + NBT * KX;                        // [62][128]
@@ -630,48 +657,58 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     lds_int* ctl = (lds_int*)(msl + 4 * TP * 8);      // [0] abort, [2..4] publish times: q, energies, context
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    const int B = a.B, Tin = a.Tin;
+    const int par = j & 1;                            // = t & 1: h_att(t) is in buffer par ^ 1, h_dec(t - 1) in buffer par
+    // everything requested before the loop state is looked at (see kernel X)
+    // ---- staging in two stages.  Every thread: its share of h_att(t) (rows < B) -> LDS in front of barrier #1 (the query and
+    // the first weight slices need it).  h_dec(t-1) is only read by the LSTM waves' later slices: they fetch it themselves and
+    // meet on an LDS counter (ctl[6]), off the chain's path.
+    constexpr int NS1 = NBT * (RNN / 4) / NTHR, NS2 = NBT * (RNN / 4) / 256;
+    f32x4 sv[NS1];
+    {
+        const float* ha = a.hatt + (size_t)(par ^ 1) * B * RNN;
+#pragma unroll
+        for (int i = 0; i < NS1; ++i) {
+            const int idx = tid + i * NTHR;           // float4 index in [NBT][1024]
+            const int b = idx / (RNN / 4), k = (idx % (RNN / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) v = *reinterpret_cast<const f32x4*>(ha + (size_t)b * RNN + k);
+            sv[i] = v;
+        }
+    }
+    auto ecol = [](int e) { return e < 4 ? e * 256 : RNN + ENC + (e - 4) * 256; };
+    f32x4 hv[NS2];                                    // LSTM waves: this thread's share of h_dec(t-1)
+    WSlice<HW> win[PF];
+    if (wave < 4) {
+        const float* hd = a.hdec + (size_t)par * B * RNN;
+#pragma unroll
+        for (int i = 0; i < NS2; ++i) {
+            const int idx = tid + i * 256;
+            const int b = idx / (RNN / 4), k = (idx % (RNN / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) v = *reinterpret_cast<const f32x4*>(hd + (size_t)b * RNN + k);
+            hv[i] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < PRE_SL; ++e) load_slice<HW, true>(win[e], a.Wd, 4ll * (blk * 4 + wave), KX, ecol(e), lane);
+    }
+    asm volatile("" ::: "memory");
     const FusedState s = *a.st;
     const int t = s.t0 + j;
     if (s.exec_t != t + 1) return;                    // X(t) decided that the loop has ended (or never ran)
-    if (*(volatile const int*)a.flags != 0) return;
-    const int B = a.B, Tin = a.Tin, max_len = s.max_len;
+    if (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const int max_len = s.max_len;
     const unsigned tag = (unsigned)t + 1;
-    const int par = t & 1;                            // h_att(t) is in buffer par ^ 1, h_dec(t - 1) in buffer par
     const FX X = fx_layout(B, Tin, ENC);
     if (wave == 0) FTR(1, 10);
     if (wave == 4) FTR(1, 0);
 
-    // ---- every thread: its share of h_att(t), h_dec(t-1) (rows < B) and of the location map -> LDS
-    f32x4 sv[NSH], lv[NSL];
-    {
-        const float* ha = a.hatt + (size_t)(par ^ 1) * B * RNN;
-        const float* hd = a.hdec + (size_t)par * B * RNN;
-#pragma unroll
-        for (int i = 0; i < NSH; ++i) {
-            const int idx = stage_index(tid + i * NTHR, blk, NSH * NTHR);      // float4 index in [NBT][2048]
-            const int b = idx / 512, k = (idx % 512) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b < B) v = *reinterpret_cast<const f32x4*>(k < RNN ? ha + (size_t)b * RNN + k : hd + (size_t)b * RNN + (k - RNN));
-            sv[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NSL; ++i) {
-            const int idx = tid + i * NTHR;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            lv[i] = idx < NL4 ? *reinterpret_cast<const f32x4*>(a.wloc + (size_t)idx * 4) : zero;
-        }
-    }
+
     auto store_staged = [&]() {
 #pragma unroll
-        for (int i = 0; i < NSH; ++i) {
-            const int idx = stage_index(tid + i * NTHR, blk, NSH * NTHR);
-            const int b = idx / 512, k = (idx % 512) * 4;
-            *reinterpret_cast<f32x4*>(xs + (size_t)b * KX + (k < RNN ? k : k + ENC)) = sv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NSL; ++i) {
+        for (int i = 0; i < NS1; ++i) {
             const int idx = tid + i * NTHR;
-            if (idx < NL4) *reinterpret_cast<f32x4*>(wl + (size_t)idx * 4) = lv[i];
+            *reinterpret_cast<f32x4*>(xs + (size_t)(idx / (RNN / 4)) * KX + (idx % (RNN / 4)) * 4) = sv[i];
         }
         for (int i = tid; i < (NBT - B) * ENC; i += NTHR) xs[(size_t)(B + i / ENC) * KX + RNN + i % ENC] = 0.f;
         if (tid < 8) ctl[tid] = 0;
@@ -683,16 +720,19 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
         constexpr int NE = 8;
         const int u = blk * 4 + wave;
         const long long row0 = 4ll * u;
-        auto ecol = [](int e) { return e < 4 ? e * 256 : RNN + ENC + (e - 4) * 256; };
-        WSlice<HW> wlate[NC], win[PF];
-#pragma unroll
-        for (int e = 0; e < PRE_SL; ++e) load_slice<HW, true>(win[e], a.Wd, row0, KX, ecol(e), lane);
+        WSlice<HW> wlate[NC];
         const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bd + 4 * u);
         const float c_old = lane < B ? a.cdec[(size_t)lane * RNN + u] : 0.f;
         asm volatile("" ::: "memory");
         store_staged();
-        __syncthreads();                              // #1: h_att(t), h_dec(t-1) staged
+        __syncthreads();                              // #1: h_att(t) staged
         if (wave == 0) FTR(1, 11);
+#pragma unroll
+        for (int i = 0; i < NS2; ++i) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<f32x4*>(xs + (size_t)(idx / (RNN / 4)) * KX + RNN + ENC + (idx % (RNN / 4)) * 4) = hv[i];
+        }
+        if (lane == 0) __hip_atomic_fetch_add(ctl + 6, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int e = PRE_SL; e < PF; ++e) load_slice<HW, true>(win[e], a.Wd, row0, KX, ecol(e), lane);
         asm volatile("" ::: "memory");
@@ -702,6 +742,10 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             WSlice<HW>& w = win[e % PF];
+            if (e == 4) {                             // first h_dec slice: every LSTM wave has stored its share
+                long long spins = 0;
+                while (lds_peek(ctl + 6) < 4 && ++spins < LDS_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+            }
             fma_slice<NBT>(acc, w.g[0], w.g[1], w.g[2], w.g[3], xs + ecol(e), KX, lane);
             asm volatile("" ::: "memory");            // the refill is requested here, not hoisted to the top
             if (e + PF < NE) load_slice<HW, true>(w, a.Wd, row0, KX, ecol(e + PF), lane);
@@ -786,6 +830,42 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     if (r == 0) FTR(1, 1);
     __syncthreads();                                  // #1
     if (r == 0) FTR(1, 2);
+    {   // the location map (31 KiB, only the energies need it): fetched by the role waves now, while the query is computed
+        // and published, instead of sitting in front of barrier #1; the four waves meet on an LDS counter
+        const int rt = tid - 256;
+        f32x4 lv[NSL];
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int idx = rt + i * 256;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            lv[i] = idx < NL4 ? *reinterpret_cast<const f32x4*>(a.wloc + (size_t)idx * 4) : zero;
+        }
+        if (!is_q) {
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int idx = rt + i * 256;
+                if (idx < NL4) *reinterpret_cast<f32x4*>(wl + (size_t)idx * 4) = lv[i];
+            }
+            if (lane == 0) __hip_atomic_fetch_add(ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            // the query wave stores its part after the publish (below)
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) asm volatile("" : "+v"(lv[i]));
+            float sm[HB];
+            const int qcol[4] = {0, 256, 512, 768};
+            role_dots<HB, 4>(sm, RQ, xs + (size_t)qrow * KX, KX, qcol, lane);
+            FTR(1, 15);
+            if (lane < HB && qrow + lane < B) publish(a.xch + X.q + (qrow + lane) * ATT + qdim, tag, pick_row<HB>(sm, lane));
+            if (lane == 0) stamp(ctl + 2);
+            FTR(1, 3);
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int idx = rt + i * 256;
+                if (idx < NL4) *reinterpret_cast<f32x4*>(wl + (size_t)idx * 4) = lv[i];
+            }
+            if (lane == 0) __hip_atomic_fetch_add(ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     if (has_ctx) {                                    // this unit's slice memory[cb][0 .. Tin)[c8 * 8 .. + 8) -> LDS (32 bytes per position);
                                                       // needed three hops from now: requested here, drained before the softmax
         const __amdgpu_buffer_rsrc_t rs_m = rsrc_of(a.memory + (size_t)cb * Tin * ENC + c8 * 8);
@@ -796,14 +876,13 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
                                                      (unsigned)tt * (ENC * 4u) + (lane & 1) * 16u, 0, 0, 0);
         }
     }
-    if (is_q) {
-        float sm[HB];
-        const int qcol[4] = {0, 256, 512, 768};
-        role_dots<HB, 4>(sm, RQ, xs + (size_t)qrow * KX, KX, qcol, lane);
-        FTR(1, 15);
-        if (lane < HB && qrow + lane < B) publish(a.xch + X.q + (qrow + lane) * ATT + qdim, tag, pick_row<HB>(sm, lane));
-        if (lane == 0) stamp(ctl + 2);
-        FTR(1, 3);
+    {   // all four parts of the location map are in LDS
+        long long spins = 0;
+        while (lds_peek(ctl + 5) < 4) {
+            if (++spins > LDS_SPIN_LIMIT) { P.give_up(); break; }
+            if ((spins & 255) == 0 && lds_peek(ctl)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
     }
     // energies of the positions this wave owns: the location term first (it only needs the previous alignments)
 #pragma unroll
