@@ -2,7 +2,7 @@
 #pragma once
 #include "engine.h"
 
-constexpr int FUSED_CHUNK = 32;          // decoder steps per enqueued chunk (= per hipGraph replay); even
+constexpr int FUSED_CHUNK = 64;          // decoder steps per enqueued chunk (= per hipGraph replay); even
 constexpr int FUSED_MAX_B = 8;
 
 // Device-resident loop state of one call (32 bytes, one scalar load per kernel).  Zero-initialised = before step 0.
@@ -27,6 +27,8 @@ struct FusedCall {
     const float* masks;                  // prenet dropout masks [B][max_len][2][256] or null
     unsigned long long* xch;             // (zeroed) fused_xch_u64(B, Tin, enc) entries
     int* flags;                          // (zeroed) [0] abort code
+    const int* bl_err;                   // encoder status word (copied into the chunk report)
+    int* report;                         // [16] chunk report written at the end of every chunk: FusedState, abort code, bl_err
     FusedState* state;                   // (zeroed, then fused_init)
     float* hatt; float* hdec;            // (zeroed) [2][B][1024] ping-pong hidden states
     float* catt; float* cdec;            // (zeroed) [B][1024]

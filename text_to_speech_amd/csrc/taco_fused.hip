@@ -1046,7 +1046,14 @@ __global__ void fused_init_kernel(FusedState* st, int B, int max_len, int early_
     st->early_stop = early_stop;
     st->pad = 0;
 }
-__global__ void fused_advance_kernel(FusedState* st) { st->t0 += FUSED_CHUNK; }
+// end of a chunk: one 64-byte report for the host (loop state, abort code, encoder status), then the next chunk's base step
+__global__ void fused_advance_kernel(FusedState* st, const int* flags, const int* bl_err, int* report) {
+    const int* sp = (const int*)st;
+    for (int i = 0; i < 8; ++i) report[i] = sp[i];
+    report[8] = flags[0];
+    report[9] = bl_err ? bl_err[0] : 0;
+    st->t0 += FUSED_CHUNK;
+}
 
 size_t lds_x(int NBT, int ENC) { return ((size_t)NBT * (2 * RNN + ENC) + (size_t)NBT * PRE + 8) * sizeof(float); }
 size_t lds_y(int NBT, int ENC, int KT) {
@@ -1082,13 +1089,13 @@ hipError_t launch_y_kt(hipStream_t st, const FusedArgs& a, int j, int KT) {
 }
 
 template <int NBT, int ENC, bool HW>
-hipError_t chunk_t(hipStream_t st, const FusedArgs& a, int KT) {
+hipError_t chunk_t(hipStream_t st, const FusedArgs& a, int KT, const int* bl_err, int* report) {
     for (int j = 0; j < FUSED_CHUNK; ++j) {
         if (hipError_t er = launch_x<NBT, ENC, HW>(st, a, j, 0); er != hipSuccess) return er;
         if (hipError_t er = launch_y_kt<NBT, ENC, HW>(st, a, j, KT); er != hipSuccess) return er;
     }
     if (hipError_t er = launch_x<NBT, ENC, HW>(st, a, FUSED_CHUNK, 1); er != hipSuccess) return er;
-    hipLaunchKernelGGL(fused_advance_kernel, dim3(1), dim3(1), 0, st, a.st);
+    hipLaunchKernelGGL(fused_advance_kernel, dim3(1), dim3(1), 0, st, a.st, (const int*)a.flags, bl_err, report);
     return hipGetLastError();
 }
 
@@ -1150,14 +1157,14 @@ int fused_enqueue_chunk(tts_hip_engine* e, hipStream_t st, const FusedCall& c) {
     hipError_t er;
     const int key = (NBT == 8 ? 4 : 0) | (enc == 768 ? 2 : 0) | (c.half_w ? 1 : 0);
     switch (key) {
-        case 0: er = chunk_t<4, 512, false>(st, a, KT); break;
-        case 1: er = chunk_t<4, 512, true>(st, a, KT); break;
-        case 2: er = chunk_t<4, 768, false>(st, a, KT); break;
-        case 3: er = chunk_t<4, 768, true>(st, a, KT); break;
-        case 4: er = chunk_t<8, 512, false>(st, a, KT); break;
-        case 5: er = chunk_t<8, 512, true>(st, a, KT); break;
-        case 6: er = chunk_t<8, 768, false>(st, a, KT); break;
-        default: er = chunk_t<8, 768, true>(st, a, KT); break;
+        case 0: er = chunk_t<4, 512, false>(st, a, KT, c.bl_err, c.report); break;
+        case 1: er = chunk_t<4, 512, true>(st, a, KT, c.bl_err, c.report); break;
+        case 2: er = chunk_t<4, 768, false>(st, a, KT, c.bl_err, c.report); break;
+        case 3: er = chunk_t<4, 768, true>(st, a, KT, c.bl_err, c.report); break;
+        case 4: er = chunk_t<8, 512, false>(st, a, KT, c.bl_err, c.report); break;
+        case 5: er = chunk_t<8, 512, true>(st, a, KT, c.bl_err, c.report); break;
+        case 6: er = chunk_t<8, 768, false>(st, a, KT, c.bl_err, c.report); break;
+        default: er = chunk_t<8, 768, true>(st, a, KT, c.bl_err, c.report); break;
     }
     HIPCHK(e, er);
     return TTS_HIP_OK;

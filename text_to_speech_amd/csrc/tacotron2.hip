@@ -1336,7 +1336,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
     size_t need = 0;
     auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
     sz(n_masks, 4); sz(try_persist ? (size_t)R * PERSIST_NPM : 1, 4);
-    sz(64, 4); sz(8, 4); sz(n_xch + 2, 8); sz(16, 4);
+    sz(64, 4); sz(8, 4); sz(16, 4); sz(n_xch + 2, 8); sz(16, 4);
     sz(2 * B * ARNN, 4); sz(B * ARNN, 4); sz(2 * B * DRNN, 4); sz(B * DRNN, 4); sz(B * enc, 4); sz(B * PRE, 4); sz(B * ATT, 4);
     sz(B * NMEL, 4); sz(R, 4); sz(R, 4); sz(R, 4); sz(B, 4); sz(B, 4); sz(2 * B, 4);
     sz(RB * NMEL, 4); sz(RB, 4); sz(RB * Tin, 4); sz(RD, 1); sz(RD * NMEL, 4); sz(RD * 512, 4); sz(RD * 512, 4);
@@ -1354,6 +1354,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
     float* d_pmfold = A.take<float>(try_persist ? (size_t)R * PERSIST_NPM : 1);
     DecState* d_state = A.take<DecState>(1);
     FusedState* d_fstate = A.take<FusedState>(1);
+    int* d_freport = A.take<int>(16);
     unsigned long long* d_xch = A.take<unsigned long long>(n_xch + 2);
     int* d_pflags = A.take<int>(16);
     float* d_hatt = A.take<float>(2 * B * ARNN);
@@ -1567,7 +1568,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         fc.B = B; fc.Tin = Tin; fc.max_len = max_len; fc.early_stop = early_stop ? 1 : 0;
         fc.win_len = win_len; fc.win_off = win_offset; fc.half_w = half_w;
         fc.memory = d_memory; fc.pm = d_pm; fc.mask = d_mask; fc.enc_len = d_enc_len; fc.masks = masks_dev;
-        fc.xch = d_xch; fc.flags = d_pflags; fc.state = d_fstate;
+        fc.xch = d_xch; fc.flags = d_pflags; fc.state = d_fstate; fc.bl_err = en->bl_err; fc.report = d_freport;
         fc.hatt = d_hatt; fc.hdec = d_hdec; fc.catt = d_catt; fc.cdec = d_cdec; fc.ctx = d_ctx;
         fc.wprev = d_wprev; fc.wcum = d_wcum; fc.mainatt = d_mainatt;
         fc.dec_out = d_decout; fc.stop_out = d_stop; fc.attn_hist = d_attn; fc.lengths = d_lengths; fc.finished = d_finished;
@@ -1612,10 +1613,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         auto enqueue = [&](int k) -> int {
             if (fgraph) HIPCHK(e, hipGraphLaunch(gexec, st));
             else if (int rc2 = fused_enqueue_chunk(e, st, fc)) return rc2;
-            ChunkReport* r = rep + (k & 1);
-            HIPCHK(e, hipMemcpyAsync(&r->st, d_fstate, sizeof(FusedState), hipMemcpyDeviceToHost, st));
-            HIPCHK(e, hipMemcpyAsync(&r->abort_code, d_pflags, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(e, hipMemcpyAsync(&r->bl_err, en->bl_err, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(e, hipMemcpyAsync(rep + (k & 1), d_freport, sizeof(ChunkReport), hipMemcpyDeviceToHost, st));
             HIPCHK(e, hipEventRecord(tc.chunk_ev[k & 1], st));
             return TTS_HIP_OK;
         };
