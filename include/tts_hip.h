@@ -85,6 +85,22 @@ int tts_hip_waveglow_infer_f16(tts_hip_engine* e, const float* mel, int B, int T
 int tts_hip_waveglow_infer_f16x3(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
                                  float* audio, int mem);
 
+/* ---- device-side sampling
+ * The reference draws WaveGlow's noise and the prenet dropout inside `infer`, on the device
+ * (architectures/waveglow_arch.py:272-274,299-302: `keras.random.normal`; tacotron2_arch.py:197-201: dropout p = 0.5).
+ * `tts_hip_random_fill` writes n floats to a DEVICE buffer `out` on `stream` (NULL = the handle's stream) without
+ * synchronizing; kind TTS_HIP_RANDOM_NORMAL: N(0, 1); kind TTS_HIP_RANDOM_PRENET_MASK: 2.0 with probability 0.5 else 0.0
+ * (the multiplicative masks `tts_hip_tacotron2_infer` takes).  Generator: Philox4x32-10, key = seed, block counter =
+ * offset + i / 4, element i = word i % 4; normals by Box-Muller on word pairs (see csrc/engine.hip; restated in
+ * oracle/philox_ref.py).  The same (seed, offset) always gives the same values; consecutive calls should advance `offset`
+ * by ceil(n / 4).
+ * `tts_hip_waveglow_infer_seeded` = WaveGlow.infer(mel, z=None, deterministic=False): z [B, T*32, 8] is generated on the
+ * device from (seed, offset) and never crosses PCIe.  precision: 0 f32, 1 f16, 2 f16x3.                               */
+enum { TTS_HIP_RANDOM_NORMAL = 0, TTS_HIP_RANDOM_PRENET_MASK = 1 };
+int tts_hip_random_fill(tts_hip_engine* e, int kind, uint64_t seed, uint64_t offset, float* out, int64_t n, void* stream);
+int tts_hip_waveglow_infer_seeded(tts_hip_engine* e, const float* mel, int B, int T, uint64_t seed, uint64_t offset,
+                                  float sigma, float* audio, int precision, int mem);
+
 /* ---- Tacotron2.infer  (architectures/tacotron2_arch.py:866-925; called at models/tts/tacotron2.py:162)
  * tokens        int32 [B, Tin], 0 = pad
  * speaker       NULL or [B, speaker_embedding_dim]
@@ -130,15 +146,24 @@ int tts_hip_tacotron2_decode(tts_hip_engine* e, const tts_hip_encoded* encoded, 
                              const float* prenet_masks, int win_len, int win_offset, int precision, float* mel,
                              float* decoder_output, float* stop_tokens, float* attention, int32_t* lengths,
                              int32_t* steps_run, int mem, void* stream);
+/* `decode` with the prenet dropout masks drawn on the device from (seed, offset) (tts_hip_random_fill, kind
+ * TTS_HIP_RANDOM_PRENET_MASK, n = B * max_len * 512): the reference's default inference path keeps this dropout on
+ * (tacotron2_arch.py:197-201), and a retry only needs another offset.                                                  */
+int tts_hip_tacotron2_decode_seeded(tts_hip_engine* e, const tts_hip_encoded* encoded, int max_len, int early_stop,
+                                    uint64_t seed, uint64_t offset, int win_len, int win_offset, int precision,
+                                    float* mel, float* decoder_output, float* stop_tokens, float* attention,
+                                    int32_t* lengths, int32_t* steps_run, int mem, void* stream);
 int tts_hip_encoded_free(tts_hip_engine* e, tts_hip_encoded* encoded);
 
-/* How the autoregressive loop (tacotron2_arch.py:710-735, K.while_loop) is executed.  mode 1 (default): one persistent,
+/* How the autoregressive loop (tacotron2_arch.py:710-735, K.while_loop) is executed.  mode 1: one persistent,
  * weight-stationary persistent kernel for the whole loop when the call shape allows it (batch <= 4, B * Tin small enough
- * for LDS, a device with >= 256 CUs that can host the whole grid), otherwise -- and always with mode 0 -- one hipGraph of 7
- * kernels per decoder step.  Both give the same results up to fp32 re-association.                                     */
+ * for LDS, a device with >= 256 CUs that can host the whole grid); mode 2: the fused two-kernel step (batch <= 8, at most
+ * 256 tokens; csrc/taco_fused.hip); mode 3 (default): persistent for 1 - 2 rows, fused for 3 - 8, whichever applies
+ * otherwise; mode 0 -- and the fallback of every other mode -- one hipGraph of 7 kernels per decoder step.  All give the
+ * same results up to fp32 re-association.                                                                              */
 int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode);
-/* Which of the two the last tts_hip_tacotron2_infer* call on this handle used: 1 persistent kernel, 0 per-step graph (also
- * after a fallback), -1 before the first call.                                                                          */
+/* Which one the last tts_hip_tacotron2_infer* call on this handle used: 2 fused step, 1 persistent kernel, 0 per-step graph
+ * (also after a fallback), -1 before the first call.                                                                          */
 int tts_hip_last_decoder_mode(const tts_hip_engine* e);
 
 /* ---- TacotronSTFT.mel_spectrogram  (utils/audio/stft.py:242-274,306-314)

@@ -132,3 +132,65 @@ def test_two_handles_decoding_at_once_share_the_gpu_correctly(gpu_engine, taco_w
                 assert np.array_equal(res[i].lengths, alone[i].lengths)
     finally:
         eng2.close()
+
+
+def test_stream_calls_order_their_conversions_on_that_stream(gpu_engine):
+    """`stream=` with inputs that need a conversion (fp16, non-contiguous, short audio to pad) produced on torch's CURRENT
+    stream: the conversion temporaries and the outputs must be ordered on `stream`, and must not be handed back to the
+    caching allocator while the engine kernels still read them (round-2 advisor finding).  Right after every call the default
+    stream allocates and scribbles over same-sized tensors, which is what recycled the temporaries before the fix."""
+    import torch
+    rng = np.random.default_rng(3)
+    B, T = 2, 24
+    mel32 = torch.from_numpy(rng.uniform(-11.5, 1.2, (B, T, 80)).astype(np.float32)).cuda()
+    z32 = torch.from_numpy(rng.standard_normal((B, T * 32, 8)).astype(np.float32)).cuda()
+    wav = torch.from_numpy(rng.uniform(-1, 1, (3, 900)).astype(np.float32)).cuda()
+    ref_audio = gpu_engine.waveglow_infer(mel32.half().float(), z=z32.half().float())
+    ref_mel = gpu_engine.mel_stft(wav.half().float())
+    s = torch.cuda.Stream()
+    for _ in range(6):
+        big = torch.randn(4096, 4096, device='cuda')
+        big = big @ big                                           # keeps the default stream busy while we enqueue
+        mel_nc = (mel32.transpose(1, 2).contiguous() + 0 * big[0, 0]).half().transpose(1, 2)    # fp16, non-contiguous, late
+        assert not mel_nc.is_contiguous()
+        wav16 = (wav + 0 * big[0, 0]).half()
+        out_a = gpu_engine.waveglow_infer(mel_nc, z=z32.half(), stream=s)
+        out_m = gpu_engine.mel_stft(wav16, stream=s)
+        junk = [torch.full_like(mel32, float('nan')), torch.full_like(z32, float('nan')),
+                torch.full((3, 1024), float('nan'), device='cuda')]
+        del junk, mel_nc, wav16
+        s.synchronize()
+        assert torch.equal(out_a, ref_audio) and torch.equal(out_m, ref_mel)
+    # seeded noise on a stream: same values as the blocking seeded call
+    a = gpu_engine.waveglow_infer(mel32, seed=3, offset=9, stream=s)
+    s.synchronize()
+    assert torch.equal(a, gpu_engine.waveglow_infer(mel32, seed=3, offset=9))
+
+
+def test_prenet_masks_drawn_on_the_device(gpu_engine, taco_weights, taco_cfg):
+    """`mask_seed` = (seed, offset): the decoder's dropout masks come from the engine's documented Philox stream; the result
+    equals the explicit-mask call with the restated stream, and (through it) the oracle.  Also through the runtime."""
+    from oracle import philox_ref, tacotron2_ref
+    from text_to_speech_amd.runtime import HipRuntime
+    tok = _tokens(3, 22, [22, 15, 9], seed=8)
+    T = 20
+    masks = philox_ref.prenet_masks(3 * T * 512, 41, 6).reshape(3, T, 2, 256)
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=T, early_stopping=False, prenet_masks=masks)
+    for mode in ('fused', 'graph'):
+        gpu_engine.set_decoder_mode(mode)
+        try:
+            enc = gpu_engine.tacotron2_encode(tok)
+            a = gpu_engine.tacotron2_decode(enc, max_len=T, early_stopping=False, mask_seed=(41, 6))
+            b = gpu_engine.tacotron2_decode(enc, max_len=T, early_stopping=False, prenet_masks=masks)
+            assert np.array_equal(a.mel, b.mel) and np.abs(a.mel - ref.mel).max() <= 1e-3
+            enc.close()
+        finally:
+            gpu_engine.set_decoder_mode('auto')
+    rt = HipRuntime('unused', engine=gpu_engine, model='tacotron2', seed=41)
+    first = rt(tok, max_length=T, early_stopping=False)                    # offset 0 of seed 41
+    m0 = philox_ref.prenet_masks(3 * T * 512, 41, 0).reshape(3, T, 2, 256)
+    ref0 = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=T, early_stopping=False, prenet_masks=m0)
+    assert np.abs(first.mel - ref0.mel).max() <= 1e-3
+    second = rt(tok, max_length=T, early_stopping=False)                   # a retry: same encoder output, other masks
+    assert rt.encoder_reuses >= 1 and not np.array_equal(first.mel, second.mel)
+    assert np.array_equal(rt(tok, max_length=T, early_stopping=False, seed=41).mel, first.mel)

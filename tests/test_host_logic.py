@@ -302,8 +302,8 @@ def test_runtime_argument_resolution_with_fake_engine():
             self.tokens = tokens
             return 'ok'
 
-        def waveglow_infer(self, mel, z=None, sigma=1.0, precision='f32'):
-            self.z, self.sigma, self.precision = z, sigma, precision
+        def waveglow_infer(self, mel, z=None, sigma=1.0, precision='f32', seed=None, offset=0):
+            self.z, self.sigma, self.precision, self.seed, self.offset = z, sigma, precision, seed, offset
             return np.zeros((mel.shape[0], mel.shape[1] * 256), np.float32)
 
     eng = Eng()
@@ -316,10 +316,19 @@ def test_runtime_argument_resolution_with_fake_engine():
     assert m.shape == (1, 370, 2, 256) and set(np.unique(m)) == {0.0, 2.0} and 0.45 < (m > 0).mean() < 0.55
     rt(tok, max_length=25, deterministic=True, attn_mask_win_len=12, attn_mask_offset=0.5)
     assert eng.kw['max_len'] == 25 and eng.kw['prenet_masks'] is None and eng.kw['attn_mask_offset'] == 6
+    # noise: drawn on the device from the runtime's (seed, running block offset); an explicit seed restarts at offset 0
     out = rt(np.zeros((2, 3, 80), np.float32), sigma=0.7)
-    assert out.shape == (2, 768) and eng.z.shape == (2, 96, 8) and eng.sigma == 0.7
+    assert out.shape == (2, 768) and eng.z is None and eng.seed == 0 and eng.sigma == 0.7
+    first = eng.offset
+    rt(np.zeros((2, 3, 80), np.float32))
+    assert eng.seed == 0 and eng.offset == first + 2 * 3 * 256 // 4
+    rt(np.zeros((2, 3, 80), np.float32), seed=9)
+    assert (eng.seed, eng.offset) == (9, 0)
+    z = np.ones((1, 96, 8), np.float32)
+    rt(np.zeros((3, 80), np.float32), z=z)
+    assert eng.z is z and eng.seed is None
     rt(np.zeros((3, 80), np.float32), deterministic=True)
-    assert eng.z is None and eng.precision == 'f32'
+    assert eng.z is None and eng.seed is None and eng.precision == 'f32'
     # vocoder precision: runtime-wide default, per-call override, validation
     rt16 = HipRuntime('fake', engine=eng, vocoder_precision='f16')
     rt16(np.zeros((1, 2, 80), np.float32), deterministic=True)

@@ -8,14 +8,14 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = 'libtts_hip.so'
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipLibraryError(RuntimeError):
@@ -36,6 +36,8 @@ SIGNATURES = {
     'tts_hip_waveglow_infer': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int]),
     'tts_hip_waveglow_infer_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int]),
     'tts_hip_waveglow_infer_f16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int]),
+    'tts_hip_random_fill': (c_int, [c_void_p, c_int, c_uint64, c_uint64, c_void_p, c_int64, c_void_p]),
+    'tts_hip_waveglow_infer_seeded': (c_int, [c_void_p, c_void_p, c_int, c_int, c_uint64, c_uint64, c_float, c_void_p, c_int, c_int]),
     'tts_hip_tacotron2_infer': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     'tts_hip_tacotron2_infer_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
@@ -48,6 +50,8 @@ SIGNATURES = {
     'tts_hip_tacotron2_encode': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, POINTER(c_void_p)]),
     'tts_hip_tacotron2_decode': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'tts_hip_tacotron2_decode_seeded': (c_int, [c_void_p, c_void_p, c_int, c_int, c_uint64, c_uint64, c_int, c_int, c_int, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'tts_hip_encoded_free': (c_int, [c_void_p, c_void_p]),
     'tts_hip_kernel_timing': (c_int, [c_void_p, c_int]),
     'tts_hip_kernel_time_us': (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),

@@ -70,7 +70,7 @@ struct WaveGlowDev {
     bool ready = false;
     WgFlowDev flow[12];
     std::vector<void*> allocs;
-    DevBuf x, acts, audio, a0p, io_mel, io_z, io_out;
+    DevBuf x, acts, audio, a0p, io_mel, io_z, io_out, io_zgen;
     bool f16_ready = false, x3_ready = false;
     DevBuf x16, acts16, a0p16, mel16;        // fp16 path: shadow of x, activations, first-layer operand, mel
 };
@@ -215,6 +215,8 @@ int melstft_run(tts_hip_engine* e, const float* d_audio, int B, int N, float* d_
 void melstft_free(tts_hip_engine* e);
 
 // shared helpers
+// n floats of device-side samples into `out` on `st` (engine.hip: Philox4x32-10; kind = TTS_HIP_RANDOM_*)
+int philox_fill(tts_hip_engine* e, float* out, long long n, uint64_t seed, uint64_t offset, int kind, hipStream_t st);
 const HostTensor* find_tensor(const tts_hip_engine* e, const std::string& name);
 // uploads a host tensor to a fresh device allocation tracked in `allocs`
 int upload(tts_hip_engine* e, const float* src, size_t n, float** dst, std::vector<void*>& allocs);

@@ -69,10 +69,72 @@ void timing_collect(tts_hip_engine* e) {
     e->timed.clear();
 }
 
+// ------------------------------------------------------------------------------------------- device-side sampling
+// The reference draws WaveGlow's noise and the prenet dropout inside `infer`, on the device
+// (/root/reference/architectures/waveglow_arch.py:272-274,299-302, tacotron2_arch.py:197-201).  Generator used here
+// (documented so that a caller can reproduce a stream; restated in oracle/philox_ref.py):
+//   Philox4x32-10 (Salmon et al., SC'11): key = (seed lo, seed hi), counter = (c lo, c hi, 0, 0) with c = offset + i / 4;
+//   element i takes word i % 4 of block c.  A word x becomes u = ((x >> 8) + 0.5) * 2^-24 in (0, 1).
+//   normals: words (0, 1) and (2, 3) of a block feed one Box-Muller pair each:
+//     r = sqrt(-2 ln u_a), (z_a, z_b) = (r cos(2 pi u_b), r sin(2 pi u_b));
+//   prenet masks (keep probability 0.5, scale 2, tacotron2_arch.py:188-203): 2.0 if the word's top bit is set else 0.0.
+namespace {
+
+struct Philox4 { uint32_t x[4]; };
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ float unit_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-8f; }
+
+// kind 0: standard normals, kind 1: prenet dropout masks.  One thread per Philox block (4 outputs).
+__global__ void philox_fill_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset, int kind) {
+    const long long blk = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk * 4 >= n) return;
+    const Philox4 w = philox4x32_10(offset + (uint64_t)blk, seed);
+    float v[4];
+    if (kind == 0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float r = sqrtf(-2.0f * logf(unit_open(w.x[2 * p])));
+            float sn, cs;
+            sincosf(6.283185307179586f * unit_open(w.x[2 * p + 1]), &sn, &cs);
+            v[2 * p] = r * cs;
+            v[2 * p + 1] = r * sn;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (w.x[k] >> 31) ? 2.0f : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (blk * 4 + k < n) out[blk * 4 + k] = v[k];
+}
+
+}  // namespace
+
+int philox_fill(tts_hip_engine* e, float* out, long long n, uint64_t seed, uint64_t offset, int kind, hipStream_t st) {
+    if (n <= 0) return TTS_HIP_OK;
+    const long long blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, out, n, seed, offset, kind);
+    HIPCHK(e, hipGetLastError());
+    return TTS_HIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 7; }
+int tts_hip_abi_version(void) { return 8; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -317,6 +379,39 @@ int tts_hip_waveglow_infer_f16(tts_hip_engine* e, const float* mel, int B, int T
 int tts_hip_waveglow_infer_f16x3(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma,
                                  float* audio, int mem) {
     return waveglow_infer_impl(e, mel, B, T, z, sigma, audio, mem, 2);
+}
+
+int tts_hip_random_fill(tts_hip_engine* e, int kind, uint64_t seed, uint64_t offset, float* out, int64_t n, void* stream) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (!out || n < 0 || (kind != TTS_HIP_RANDOM_NORMAL && kind != TTS_HIP_RANDOM_PRENET_MASK))
+        return set_err(e, TTS_HIP_EINVAL, "random_fill: bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    return philox_fill(e, out, (long long)n, seed, offset, kind, stream ? (hipStream_t)stream : e->stream);
+}
+
+// WaveGlow.infer with the noise drawn on the device (the reference's default: z = None, deterministic = False).
+int tts_hip_waveglow_infer_seeded(tts_hip_engine* e, const float* mel, int B, int T, uint64_t seed, uint64_t offset,
+                                  float sigma, float* audio, int precision, int mem) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (precision < 0 || precision > 2) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer_seeded: precision must be 0 (f32), 1 (f16) or 2 (f16x3)");
+    if (B <= 0 || T <= 0 || (long long)B * T * 32 > (1ll << 30)) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer_seeded: bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t n_z = (size_t)B * T * 32 * 8;
+    HIPCHK(e, e->wg.io_zgen.ensure(n_z * 4));
+    int rc = philox_fill(e, e->wg.io_zgen.f(), (long long)n_z, seed, offset, TTS_HIP_RANDOM_NORMAL, e->stream);
+    if (rc) return rc;
+    // the generated noise is a device buffer whatever `mem` says about mel / audio
+    if (mem == TTS_HIP_MEM_DEVICE) return waveglow_infer_impl(e, mel, B, T, e->wg.io_zgen.f(), sigma, audio, mem, precision);
+    if (mem != TTS_HIP_MEM_HOST) return set_err(e, TTS_HIP_EINVAL, "waveglow_infer_seeded: bad mem kind %d", mem);
+    const size_t n_mel = (size_t)B * T * 80, n_out = (size_t)B * T * 256;
+    HIPCHK(e, e->wg.io_mel.ensure(n_mel * 4));
+    HIPCHK(e, e->wg.io_out.ensure(n_out * 4));
+    HIPCHK(e, hipMemcpyAsync(e->wg.io_mel.p, mel, n_mel * 4, hipMemcpyHostToDevice, e->stream));
+    rc = waveglow_infer_impl(e, e->wg.io_mel.f(), B, T, e->wg.io_zgen.f(), sigma, e->wg.io_out.f(), TTS_HIP_MEM_DEVICE, precision);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(audio, e->wg.io_out.p, n_out * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return TTS_HIP_OK;
 }
 
 // Device-pointer variants on a caller stream: enqueue and return (no synchronization).  Same arithmetic as the calls above.

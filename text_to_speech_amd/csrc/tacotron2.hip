@@ -1295,7 +1295,7 @@ static int tacotron2_encode_impl(tts_hip_engine* e, const int32_t* tokens, int B
 static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, int max_len, int early_stop,
                                  const float* prenet_masks, int win_len, int win_offset, float* mel,
                                  float* decoder_output, float* stop_tokens, float* attention, int32_t* lengths,
-                                 int32_t* steps_run, int mem, bool half_w) {
+                                 int32_t* steps_run, int mem, bool half_w, const uint64_t* mask_seed = nullptr) {
     Tacotron2Dev& tc = e->taco;
     if (!tc.ready) return set_err(e, TTS_HIP_ENOTREADY, "tacotron2 weights not finalized");
     if (!en || !en->buf.p || en->B <= 0 || max_len <= 0) return set_err(e, TTS_HIP_EINVAL, "tacotron2_decode: bad argument");
@@ -1331,7 +1331,8 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         else try_persist = false;
     }
     const size_t n_xch = std::max(try_persist ? persist_xch_u64(B, Tin) : (size_t)0, try_fused ? fused_xch_u64(B, Tin, enc) : (size_t)0);
-    const size_t n_masks = prenet_masks ? (size_t)RB * 2 * PRE : 1;
+    const bool with_masks = prenet_masks != nullptr || mask_seed != nullptr;
+    const size_t n_masks = with_masks ? (size_t)RB * 2 * PRE : 1;
     const size_t conv_rows = (size_t)std::min<long long>(RD, 32768);     // 512 tiles x 64 rows at most
     size_t need = 0;
     auto sz = [&](size_t n, size_t el) { need = (need + 255) / 256 * 256 + n * el; };
@@ -1400,6 +1401,9 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
     const float* masks_dev = nullptr;
     if (prenet_masks) {
         HIPCHK(e, hipMemcpyAsync(d_masks, prenet_masks, (size_t)RD * 2 * PRE * 4, kin, st));
+        masks_dev = d_masks;
+    } else if (mask_seed) {                                 // drawn on the device, straight into the workspace
+        if ((rc = philox_fill(e, d_masks, (long long)RD * 2 * PRE, mask_seed[0], mask_seed[1], TTS_HIP_RANDOM_PRENET_MASK, st))) return rc;
         masks_dev = d_masks;
     }
 
@@ -1594,7 +1598,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         constexpr const char* trace_file = nullptr;
 #endif
         if (fgraph && !trace_file) {
-            const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, prenet_masks ? 1 : 0, win_len, win_offset,
+            const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, with_masks ? 1 : 0, win_len, win_offset,
                                   half_w ? 1 : 0, layout_id | 4};
             if ((rc = cached_graph(key, [&]() { return fused_enqueue_chunk(e, st, fc); }, &gexec))) return rc;
         }
@@ -1671,7 +1675,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
 #endif
         hipGraphExec_t gexec = nullptr;
         if (use_graph) {
-            const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, prenet_masks ? 1 : 0, win_len, win_offset,
+            const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, with_masks ? 1 : 0, win_len, win_offset,
                                   half_w ? 1 : 0, layout_id};
             auto enqueue = [&]() -> int {
                 int crc = TTS_HIP_OK;
@@ -1786,6 +1790,18 @@ extern "C" int tts_hip_tacotron2_decode(tts_hip_engine* e, const tts_hip_encoded
     StreamScope scope(e, stream);
     return tacotron2_decode_impl(e, encoded, max_len, early_stop, prenet_masks, win_len, win_offset, mel, decoder_output,
                                  stop_tokens, attention, lengths, steps_run, mem, precision == 1);
+}
+
+extern "C" int tts_hip_tacotron2_decode_seeded(tts_hip_engine* e, const tts_hip_encoded* encoded, int max_len, int early_stop,
+                                               uint64_t seed, uint64_t offset, int win_len, int win_offset, int precision,
+                                               float* mel, float* decoder_output, float* stop_tokens, float* attention,
+                                               int32_t* lengths, int32_t* steps_run, int mem, void* stream) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (precision != 0 && precision != 1) return set_err(e, TTS_HIP_EINVAL, "tacotron2_decode_seeded: precision must be 0 (f32) or 1 (f16 weights)");
+    StreamScope scope(e, stream);
+    const uint64_t ms[2] = {seed, offset};
+    return tacotron2_decode_impl(e, encoded, max_len, early_stop, nullptr, win_len, win_offset, mel, decoder_output, stop_tokens,
+                                 attention, lengths, steps_run, mem, precision == 1, ms);
 }
 
 extern "C" int tts_hip_encoded_free(tts_hip_engine* e, tts_hip_encoded* encoded) {

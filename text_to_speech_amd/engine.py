@@ -97,6 +97,49 @@ class HipEngine:
             return None
         return ctypes.c_void_p(int(stream.cuda_stream))
 
+    def _enter_stream(self, stream):
+        """Context for the `stream=` paths: `stream` first waits for what torch's current stream has queued (the caller's
+        inputs may still be in flight there), then becomes torch's current stream, so that every conversion, padding and
+        output allocation of the call is ordered on the stream the engine kernels run on."""
+        torch = self._torch()
+        stream.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(stream)
+
+    @staticmethod
+    def _used_on(stream, *tensors):
+        """Tensors passed to the engine by pointer and read asynchronously on `stream`: tell the caching allocator, so that
+        a temporary freed when the call returns is not handed out again while the kernels still read it."""
+        for t in tensors:
+            if t is not None:
+                t.record_stream(stream)
+
+    # ------------------------------------------------------------------ device-side sampling
+    def random_normal(self, shape, seed: int, offset: int = 0, stream=None):
+        """N(0, 1) float32 tensor of `shape` on this engine's GPU, drawn on the device (Philox4x32-10 + Box-Muller,
+        tts_hip_random_fill); the same (seed, offset) always gives the same values."""
+        return self._random(0, shape, seed, offset, stream)
+
+    def random_prenet_masks(self, B: int, max_len: int, seed: int, offset: int = 0, stream=None):
+        """Prenet dropout masks [B, max_len, 2, 256] (2.0 with probability 0.5, else 0.0) drawn on the device."""
+        return self._random(1, (int(B), int(max_len), 2, 256), seed, offset, stream)
+
+    def _random(self, kind, shape, seed, offset, stream):
+        torch = self._torch()
+        dev = torch.device('cuda', self.device)
+        u64 = lambda v: ctypes.c_uint64(int(v) & 0xFFFFFFFFFFFFFFFF)
+        if stream is not None:
+            with self._enter_stream(stream):
+                out = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+            sp = ctypes.c_void_p(int(stream.cuda_stream))
+        else:
+            out = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+            sp = None
+        self._check(self._lib.tts_hip_random_fill(self._h, kind, u64(seed), u64(offset), ctypes.c_void_p(out.data_ptr()),
+                                                  out.numel(), sp), 'random_fill')
+        if stream is None:
+            self.synchronize()
+        return out
+
     # ------------------------------------------------------------------ weights
     def set_tensor(self, name: str, array) -> None:
         a = np.ascontiguousarray(array, dtype=np.float32)
@@ -118,39 +161,59 @@ class HipEngine:
         return bool(self._lib.tts_hip_has_model(self._h, model.encode()))
 
     # ------------------------------------------------------------------ WaveGlow
-    def waveglow_infer(self, mel, z=None, sigma: float = 1.0, precision: str = 'f32', stream=None):
+    def waveglow_infer(self, mel, z=None, sigma: float = 1.0, precision: str = 'f32', stream=None, seed=None, offset: int = 0):
         """mel [B, T, 80] (+ optional z [B, T*32, 8]) -> audio [B, T*256].  precision: 'f32' (exact fp32 MFMA), 'f16x3'
-        (split fp16: fp32-class accuracy, ~3x faster) or 'f16' (fp16 operands).  `stream` (a torch.cuda.Stream, device
-        tensors only): enqueue on that stream and return without waiting (tts_hip_waveglow_infer_async)."""
+        (split fp16: fp32-class accuracy, ~3x faster) or 'f16' (fp16 operands).  `seed` (with z=None): the noise is drawn
+        on the device from (seed, offset) -- the reference's default `z=None, deterministic=False`
+        (waveglow_arch.py:272-274,299-302) without a host-made tensor crossing PCIe; z=None and seed=None: zeros
+        (`deterministic=True`).  `stream` (a torch.cuda.Stream, device tensors only): enqueue on that stream and return
+        without waiting (tts_hip_waveglow_infer_async)."""
         fns = {'f32': self._lib.tts_hip_waveglow_infer, 'f16': self._lib.tts_hip_waveglow_infer_f16,
                'f16x3': self._lib.tts_hip_waveglow_infer_f16x3}
         if precision not in fns:
             raise ValueError(f"precision must be one of {tuple(fns)}, got {precision!r}")
+        if z is not None and seed is not None:
+            raise ValueError('pass either z or seed, not both')
         fn = fns[precision]
+        pcode = {'f32': 0, 'f16': 1, 'f16x3': 2}[precision]
+        u64 = lambda v: ctypes.c_uint64(int(v) & 0xFFFFFFFFFFFFFFFF)
         if _is_torch_cuda(mel):
             torch = self._torch()
-            mel = mel.to(torch.float32).contiguous()
             if mel.dim() != 3 or mel.shape[2] != 80:
                 raise ValueError(f'mel must be [B, T, 80], got {tuple(mel.shape)}')
             B, T = int(mel.shape[0]), int(mel.shape[1])
-            zp = None
-            if z is not None:
-                z = z.to(device=mel.device, dtype=torch.float32).contiguous()
-                if tuple(z.shape) != (B, T * 32, 8):
-                    raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {tuple(z.shape)}')
-                zp = ctypes.c_void_p(z.data_ptr())
+            if z is not None and tuple(z.shape) != (B, T * 32, 8):
+                raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {tuple(z.shape)}')
             self._check_device(mel, z)
+
+            def prepared():
+                m = mel.to(torch.float32).contiguous()
+                zz = None if z is None else z.to(device=mel.device, dtype=torch.float32).contiguous()
+                return m, zz, torch.empty((B, T * 256), dtype=torch.float32, device=mel.device)
+
             if stream is not None:
-                with torch.cuda.stream(stream):
-                    out = torch.empty((B, T * 256), dtype=torch.float32, device=mel.device)
+                with self._enter_stream(stream):
+                    m, zz, out = prepared()
+                    if zz is None and seed is not None:
+                        zz = torch.empty((B, T * 32, 8), dtype=torch.float32, device=mel.device)
+                        self._check(self._lib.tts_hip_random_fill(self._h, 0, u64(seed), u64(offset),
+                                                                  ctypes.c_void_p(zz.data_ptr()), zz.numel(),
+                                                                  ctypes.c_void_p(int(stream.cuda_stream))), 'random_fill')
+                self._used_on(stream, mel, z, m, zz, out)
                 self._check(self._lib.tts_hip_waveglow_infer_async(
-                    self._h, ctypes.c_void_p(mel.data_ptr()), B, T, zp, float(sigma), ctypes.c_void_p(out.data_ptr()),
-                    {'f32': 0, 'f16': 1, 'f16x3': 2}[precision], self._order_after_torch(stream)), 'waveglow_infer_async')
+                    self._h, ctypes.c_void_p(m.data_ptr()), B, T, None if zz is None else ctypes.c_void_p(zz.data_ptr()),
+                    float(sigma), ctypes.c_void_p(out.data_ptr()), pcode, ctypes.c_void_p(int(stream.cuda_stream))),
+                    'waveglow_infer_async')
                 return out
-            out = torch.empty((B, T * 256), dtype=torch.float32, device=mel.device)
+            m, zz, out = prepared()
             self._order_after_torch()
-            self._check(fn(self._h, ctypes.c_void_p(mel.data_ptr()), B, T, zp, float(sigma),
-                           ctypes.c_void_p(out.data_ptr()), MEM_DEVICE), 'waveglow_infer')
+            if zz is None and seed is not None:
+                self._check(self._lib.tts_hip_waveglow_infer_seeded(
+                    self._h, ctypes.c_void_p(m.data_ptr()), B, T, u64(seed), u64(offset), float(sigma),
+                    ctypes.c_void_p(out.data_ptr()), pcode, MEM_DEVICE), 'waveglow_infer_seeded')
+                return out
+            self._check(fn(self._h, ctypes.c_void_p(m.data_ptr()), B, T, None if zz is None else ctypes.c_void_p(zz.data_ptr()),
+                           float(sigma), ctypes.c_void_p(out.data_ptr()), MEM_DEVICE), 'waveglow_infer')
             return out
         if stream is not None:
             raise ValueError('stream= needs device tensors')
@@ -165,6 +228,11 @@ class HipEngine:
                 raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {z.shape}')
             zp = z.ctypes.data_as(ctypes.c_void_p)
         out = np.empty((B, T * 256), dtype=np.float32)
+        if zp is None and seed is not None:
+            self._check(self._lib.tts_hip_waveglow_infer_seeded(
+                self._h, mel.ctypes.data_as(ctypes.c_void_p), B, T, u64(seed), u64(offset), float(sigma),
+                out.ctypes.data_as(ctypes.c_void_p), pcode, MEM_HOST), 'waveglow_infer_seeded')
+            return out
         self._check(fn(self._h, mel.ctypes.data_as(ctypes.c_void_p), B, T, zp, float(sigma),
                        out.ctypes.data_as(ctypes.c_void_p), MEM_HOST), 'waveglow_infer')
         return out
@@ -234,9 +302,19 @@ class HipEngine:
         dev = _is_torch_cuda(tokens)
         if dev:
             torch = self._torch()
-            tok = tokens.to(torch.int32).contiguous()
-            spk = None if speaker is None else speaker.to(device=tok.device, dtype=torch.float32).contiguous()
-            self._check_device(tok, spk)
+            self._check_device(tokens, speaker)
+
+            def convert():
+                t_ = tokens.to(torch.int32).contiguous()
+                s_ = None if speaker is None else speaker.to(device=tokens.device, dtype=torch.float32).contiguous()
+                return t_, s_
+
+            if stream is not None:
+                with self._enter_stream(stream):
+                    tok, spk = convert()
+                self._used_on(stream, tokens, speaker, tok, spk)
+            else:
+                tok, spk = convert()
             ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
             sp = self._order_after_torch(stream)
         else:
@@ -256,9 +334,13 @@ class HipEngine:
 
     def tacotron2_decode(self, encoded, max_len: int = 1000, early_stopping: bool = True, prenet_masks=None,
                          attn_mask_win_len=None, attn_mask_offset: int = 0, want_attention=True, precision: str = 'f32',
-                         stream=None):
+                         stream=None, mask_seed=None):
         """Decoder loop + postnet on an `EncodedBatch`; may be called repeatedly (new dropout masks, other `max_len`).
-        Returns after `stream` (or the engine's stream) has drained: the loop's length is decided on the GPU."""
+        `mask_seed` = (seed, offset): the prenet dropout masks are drawn on the device (tts_hip_tacotron2_decode_seeded)
+        instead of being passed in.  Returns after `stream` (or the engine's stream) has drained: the loop's length is
+        decided on the GPU."""
+        if mask_seed is not None and prenet_masks is not None:
+            raise ValueError('pass either prenet_masks or mask_seed, not both')
         if precision not in ('f32', 'f16'):
             raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
         if encoded.engine is not self or encoded.handle is None:
@@ -267,14 +349,21 @@ class HipEngine:
         max_len = int(max_len)
         if max_len <= 0:
             raise ValueError('max_len must be positive')
+        scope = None
         if dev:
             torch = self._torch()
             device = torch.device('cuda', self.device)
             mk = lambda shape, dt=None: torch.zeros(shape, dtype=dt or torch.float32, device=device)
             ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+            if stream is not None:                   # conversions and zero-filled outputs are ordered on `stream` itself
+                scope = self._enter_stream(stream)
+                scope.__enter__()
             if prenet_masks is not None:
-                prenet_masks = prenet_masks.to(device=device, dtype=torch.float32).contiguous()
                 self._check_device(prenet_masks)
+                masks_in = prenet_masks
+                prenet_masks = prenet_masks.to(device=device, dtype=torch.float32).contiguous()
+                if stream is not None:
+                    self._used_on(stream, masks_in, prenet_masks)
             i32 = torch.int32
         else:
             mk = lambda shape, dt=None: np.zeros(shape, dtype=dt or np.float32)
@@ -287,13 +376,23 @@ class HipEngine:
         mel, dec, stop = mk((B, max_len, 80)), mk((B, max_len, 80)), mk((B, max_len))
         attn = mk((B, max_len, Tin)) if want_attention else None
         lengths = mk((B,), i32)
+        if scope is not None:
+            scope.__exit__(None, None, None)
+            self._used_on(stream, mel, dec, stop, attn, lengths)
         steps = ctypes.c_int32(0)
         sp = self._order_after_torch(stream) if dev else None
         win = int(attn_mask_win_len) if attn_mask_win_len is not None else 0
-        self._check(self._lib.tts_hip_tacotron2_decode(
-            self._h, encoded.handle, max_len, 1 if early_stopping else 0, ptr(prenet_masks), win, int(attn_mask_offset),
-            1 if precision == 'f16' else 0, ptr(mel), ptr(dec), ptr(stop), ptr(attn), ptr(lengths),
-            ctypes.cast(ctypes.byref(steps), ctypes.c_void_p), MEM_DEVICE if dev else MEM_HOST, sp), 'tacotron2_decode')
+        if mask_seed is not None:
+            u64 = lambda v: ctypes.c_uint64(int(v) & 0xFFFFFFFFFFFFFFFF)
+            self._check(self._lib.tts_hip_tacotron2_decode_seeded(
+                self._h, encoded.handle, max_len, 1 if early_stopping else 0, u64(mask_seed[0]), u64(mask_seed[1]), win,
+                int(attn_mask_offset), 1 if precision == 'f16' else 0, ptr(mel), ptr(dec), ptr(stop), ptr(attn), ptr(lengths),
+                ctypes.cast(ctypes.byref(steps), ctypes.c_void_p), MEM_DEVICE if dev else MEM_HOST, sp), 'tacotron2_decode_seeded')
+        else:
+            self._check(self._lib.tts_hip_tacotron2_decode(
+                self._h, encoded.handle, max_len, 1 if early_stopping else 0, ptr(prenet_masks), win, int(attn_mask_offset),
+                1 if precision == 'f16' else 0, ptr(mel), ptr(dec), ptr(stop), ptr(attn), ptr(lengths),
+                ctypes.cast(ctypes.byref(steps), ctypes.c_void_p), MEM_DEVICE if dev else MEM_HOST, sp), 'tacotron2_decode')
         self.last_steps = int(steps.value)
         return Tacotron2InferenceOutput(decoder_output=dec, mel=mel, stop_tokens=stop, attention_weights=attn,
                                         lengths=lengths)
@@ -318,22 +417,28 @@ class HipEngine:
         device tensors only): enqueue there and return without waiting."""
         if _is_torch_cuda(audio):
             torch = self._torch()
-            a = audio.to(torch.float32)
-            if a.dim() == 1:
-                a = a[None]
-            if a.shape[1] < 1024:
-                a = torch.nn.functional.pad(a, (0, 1024 - a.shape[1]))
-            a = a.contiguous()
-            B, N = int(a.shape[0]), int(a.shape[1])
-            self._check_device(a)
+            self._check_device(audio)
+
+            def prepared():
+                a_ = audio.to(torch.float32)
+                if a_.dim() == 1:
+                    a_ = a_[None]
+                if a_.shape[1] < 1024:
+                    a_ = torch.nn.functional.pad(a_, (0, 1024 - a_.shape[1]))
+                a_ = a_.contiguous()
+                return a_, torch.empty((int(a_.shape[0]), int(a_.shape[1]) // 256 + 1, 80), dtype=torch.float32, device=a_.device)
+
             if stream is not None:
-                with torch.cuda.stream(stream):
-                    out = torch.empty((B, N // 256 + 1, 80), dtype=torch.float32, device=a.device)
+                with self._enter_stream(stream):
+                    a, out = prepared()
+                self._used_on(stream, audio, a, out)
+                B, N = int(a.shape[0]), int(a.shape[1])
                 self._check(self._lib.tts_hip_mel_stft_async(self._h, ctypes.c_void_p(a.data_ptr()), B, N,
                                                              ctypes.c_void_p(out.data_ptr()), self._order_after_torch(stream)),
                             'mel_stft_async')
                 return out
-            out = torch.empty((B, N // 256 + 1, 80), dtype=torch.float32, device=a.device)
+            a, out = prepared()
+            B, N = int(a.shape[0]), int(a.shape[1])
             self._order_after_torch()
             self._check(self._lib.tts_hip_mel_stft(self._h, ctypes.c_void_p(a.data_ptr()), B, N,
                                                    ctypes.c_void_p(out.data_ptr()), MEM_DEVICE), 'mel_stft')

@@ -19,6 +19,8 @@ class TTSPipeline:
         self.vocoder_precision = vocoder_precision      # 'f16': BASELINE.json configs 3 / 5
         self.synthesizer_precision = synthesizer_precision
         self._rng = np.random.default_rng(seed)
+        self._seed = int(seed) if seed is not None else int(np.random.SeedSequence().generate_state(2, np.uint32).view(np.uint64)[0])
+        self._offset = 0                                # running block offset in the engine's device-side Philox stream
 
     def synthesize_tokens(self, tokens, speaker=None, max_length=10.0, deterministic=False, prenet_masks=None, z=None,
                           sigma=1.0, early_stopping=True, round_frames_to=8):
@@ -33,10 +35,10 @@ class TTSPipeline:
         n_tok = int((tok != 0).sum(dim=1).max())
         max_len = int(np.float32(n_tok) * np.float32(max_length)) if isinstance(max_length, float) else int(max_length)
         max_len = max(1, max_len)
-        if prenet_masks is None and not deterministic:
-            from .runtime import sample_prenet_masks
-            prenet_masks = sample_prenet_masks(self._rng, B, max_len)
-        if prenet_masks is not None:
+        if prenet_masks is None and not deterministic:          # drawn on the device (engine's Philox stream)
+            prenet_masks = eng.random_prenet_masks(B, max_len, self._seed, self._offset)
+            self._offset += (B * max_len * 512 + 3) // 4
+        elif prenet_masks is not None:
             prenet_masks = as_dev(prenet_masks, torch.float32)
         if speaker is not None:
             speaker = as_dev(speaker, torch.float32)
@@ -54,10 +56,13 @@ class TTSPipeline:
         valid = torch.arange(T, device=dev)[None, :] < lengths[:, None]
         mel = torch.where(valid[:, :, None], mel, torch.full_like(mel, PAD_MEL_VALUE))
         if z is None and not deterministic:
-            z = torch.from_numpy(self._rng.standard_normal((B, T * 32, 8)).astype(np.float32)).to(dev)
-        elif z is not None:
-            z = as_dev(z, torch.float32)[:, :T * 32]
-        audio = eng.waveglow_infer(mel.contiguous(), z=z, sigma=sigma, precision=self.vocoder_precision)
+            audio = eng.waveglow_infer(mel.contiguous(), sigma=sigma, precision=self.vocoder_precision, seed=self._seed,
+                                       offset=self._offset)
+            self._offset += (B * T * 256 + 3) // 4
+        else:
+            if z is not None:
+                z = as_dev(z, torch.float32)[:, :T * 32]
+            audio = eng.waveglow_infer(mel.contiguous(), z=z, sigma=sigma, precision=self.vocoder_precision)
         audio_h = audio.cpu().numpy()
         n = lengths.cpu().numpy()
         return [audio_h[b, :int(n[b]) * 256].copy() for b in range(B)], n, steps

@@ -12,8 +12,11 @@ Call contracts honoured:
              Tacotron2InferenceOutput, tacotron2_arch.py:52-56); unknown kwargs are ignored.
   WaveGlow   models/tts/waveglow.py:82-132 compiled_infer(float32[B, T, 80], **kw) -> float32[B, T*256];
              honours z / sigma / deterministic (waveglow_arch.py:244).
-Randomness (the reference samples prenet dropout and z inside the graph) is explicit here: pass `prenet_masks` / `z`,
-or `deterministic=True`, or a `seed` for the documented numpy generator (`sample_prenet_masks`; N(0, 1) noise).
+Randomness: like the reference (prenet dropout and z are sampled inside the graph, on the device:
+tacotron2_arch.py:197-201, waveglow_arch.py:272-274,299-302) the default path draws both ON THE GPU -- the engine's
+documented Philox4x32-10 stream (include/tts_hip.h, oracle/philox_ref.py), keyed by the runtime's seed and a running block
+offset -- so no host-made tensor crosses PCIe.  Explicit control stays: pass `prenet_masks` / `z`, or `deterministic=True`,
+or `seed=` (that call then starts at offset 0 of that seed's stream and is reproducible).
 """
 from __future__ import annotations
 
@@ -88,7 +91,10 @@ class HipRuntime(Runtime):
     def __init__(self, path, *, model=None, engine=None, reload=False, device=0, seed=None, **kwargs):
         super().__init__(path, engine=engine, reload=reload, device=device, **kwargs)
         self.model = model
-        self._rng = np.random.default_rng(seed)
+        self._rng = np.random.default_rng(seed)       # host generator (only `sample_prenet_masks` callers use it)
+        # device stream: key + running block offset (a block = 4 values); an unseeded runtime takes its key from the OS
+        self._seed = int(seed) if seed is not None else int(np.random.SeedSequence().generate_state(2, np.uint32).view(np.uint64)[0])
+        self._offset = 0
         self.max_decoder_steps = int(kwargs.get('max_decoder_steps', 2000))
         self.vocoder_precision = kwargs.get('vocoder_precision', 'f32')
         if self.vocoder_precision not in ('f32', 'f16', 'f16x3'):
@@ -144,45 +150,66 @@ class HipRuntime(Runtime):
         else:
             tokens, speaker = inputs, None
         dev = _is_torch_cuda(tokens)
-        tok_np = tokens.detach().cpu().numpy() if dev else np.asarray(tokens)
-        if tok_np.ndim == 1:
-            tok_np = tok_np[None]
+        if not dev:
+            tokens = np.asarray(tokens)
+        if tokens.ndim == 1:
             tokens = tokens[None]
-        B = tok_np.shape[0]
-        n_tok = int((tok_np != 0).sum(axis=1).max())
+        B = int(tokens.shape[0])
         if max_length is None:                      # :886-887 (hparam max_decoder_steps)
             max_len = self.max_decoder_steps
         elif isinstance(max_length, float):         # :888-892
+            n_tok = int((tokens != 0).sum(1).max())
             max_len = int(np.float32(n_tok) * np.float32(max_length))
         else:
             max_len = int(max_length)
         max_len = max(1, max_len)
         if attn_mask_win_len is not None and isinstance(attn_mask_offset, float):   # :894-897
             attn_mask_offset = int(np.float32(attn_mask_win_len) * np.float32(attn_mask_offset))
+        mask_seed = None
         if prenet_masks is None and not deterministic:
-            rng = self._rng if seed is None else np.random.default_rng(seed)
-            prenet_masks = sample_prenet_masks(rng, B, max_len)
-            if dev:
-                import torch
-                prenet_masks = torch.from_numpy(prenet_masks).to(tokens.device)
-        spk_np = None if speaker is None else (speaker.detach().cpu().numpy() if _is_torch_cuda(speaker) else np.asarray(speaker))
-        key = (tok_np.shape, tok_np.astype(np.int32).tobytes(), None if spk_np is None else spk_np.astype(np.float32).tobytes(),
-               bool(dev))
-        if self._encoded is not None and self._encoded[0] == key and hasattr(self.engine, 'tacotron2_decode'):
-            self.encoder_reuses += 1
-        elif hasattr(self.engine, 'tacotron2_encode'):
-            if self._encoded is not None:
-                self._encoded[1].close()
-            self._encoded = (key, self.engine.tacotron2_encode(tokens if dev else tok_np, speaker=speaker))
-        else:                                                    # an engine object without the split entry points
+            if seed is not None:
+                mask_seed = (int(seed), 0)
+            else:
+                mask_seed = (self._seed, self._offset)
+                self._offset += (B * max_len * 512 + 3) // 4
+        # encoder reuse (the reference retries a sentence with fresh dropout, models/tts/tacotron2.py:160-179): device inputs
+        # are recognised by identity and version (no copy), host inputs by their bytes
+        if dev:
+            key = ('dev', tokens.data_ptr(), tokens._version, tuple(tokens.shape),
+                   None if speaker is None else (speaker.data_ptr(), getattr(speaker, '_version', 0), tuple(speaker.shape)))
+        else:
+            spk_np = None if speaker is None else (speaker.detach().cpu().numpy() if _is_torch_cuda(speaker) else np.asarray(speaker))
+            key = ('host', tokens.shape, tokens.astype(np.int32).tobytes(),
+                   None if spk_np is None else spk_np.astype(np.float32).tobytes())
+        if not hasattr(self.engine, 'tacotron2_encode'):        # an engine object without the split entry points
+            if mask_seed is not None and prenet_masks is None:
+                prenet_masks = sample_prenet_masks(np.random.default_rng(mask_seed[0] + mask_seed[1]), B, max_len)
             return self.engine.tacotron2_infer(
-                tokens if dev else tok_np, speaker=speaker, max_len=max_len, early_stopping=bool(early_stopping),
+                tokens, speaker=speaker, max_len=max_len, early_stopping=bool(early_stopping),
                 prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
                 precision=precision or self.synthesizer_precision)
-        return self.engine.tacotron2_decode(
-            self._encoded[1], max_len=max_len, early_stopping=bool(early_stopping), prenet_masks=prenet_masks,
-            attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
-            precision=precision or self.synthesizer_precision)
+        if self._encoded is not None and self._encoded[0] == key:
+            self.encoder_reuses += 1
+        else:
+            self._drop_encoded()
+            self._encoded = (key, self.engine.tacotron2_encode(tokens, speaker=speaker))
+        try:
+            return self.engine.tacotron2_decode(
+                self._encoded[1], max_len=max_len, early_stopping=bool(early_stopping), prenet_masks=prenet_masks,
+                attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
+                precision=precision or self.synthesizer_precision, mask_seed=mask_seed)
+        except Exception:
+            # a failed decode may have been caused by the encoded batch itself (e.g. the encoder's block exchange timed out and
+            # left its status in the buffer): a retry must run the encoder again, not reuse it
+            self._drop_encoded()
+            raise
+
+    def _drop_encoded(self):
+        if self._encoded is not None:
+            try:
+                self._encoded[1].close()
+            finally:
+                self._encoded = None
 
     # ------------------------------------------------------------------ WaveGlow.infer (waveglow_arch.py:244-306)
     def waveglow_infer(self, mel, z=None, sigma=1.0, deterministic=False, seed=None, precision=None, **_ignored):
@@ -193,16 +220,13 @@ class HipRuntime(Runtime):
             mel = mel[None]
         B, T = int(mel.shape[0]), int(mel.shape[1])
         if z is None and not deterministic:
-            if dev:
-                import torch
-                gen = None
-                if seed is not None:
-                    gen = torch.Generator(device=mel.device)
-                    gen.manual_seed(int(seed))
-                z = torch.randn((B, T * 32, 8), dtype=torch.float32, device=mel.device, generator=gen)
+            if seed is not None:
+                zs, zo = int(seed), 0
             else:
-                rng = self._rng if seed is None else np.random.default_rng(seed)
-                z = rng.standard_normal((B, T * 32, 8)).astype(np.float32)
+                zs, zo = self._seed, self._offset
+                self._offset += (B * T * 256 + 3) // 4
+            return self.engine.waveglow_infer(mel, sigma=float(sigma), precision=precision or self.vocoder_precision,
+                                              seed=zs, offset=zo)
         return self.engine.waveglow_infer(mel, z=z, sigma=float(sigma), precision=precision or self.vocoder_precision)
 
 
