@@ -229,6 +229,58 @@ def test_config4_sv2tts_shard_through_rccl_world1(wg_weights, wg_cfg):
         assert e <= WAVE_RMS_TOL
 
 
+def test_config4_full_batch_of_32_through_rccl_world1(wg_weights, wg_cfg):
+    """BASELINE config 4 in full on one GPU: 32 SV2TTS utterances (enc 768) through scatter -> `TTSPipeline.shard_fn` ->
+    gather on `nccl` at world size 1 (what `bench.py` times as its config-4 job).  Rows are independent: the batch of 32
+    (per-step graph, four LSTM passes per step) must equal the same utterances synthesized as four batches of 8 (fused
+    two-kernel step), and two of the rows are checked against the oracle."""
+    import torch
+    import torch.distributed as dist
+    from oracle import tacotron2_ref, waveglow_ref
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import Tacotron2Config
+    from text_to_speech_amd.distributed import partition, synthesize_sharded
+    from text_to_speech_amd.pipeline import TTSPipeline
+    cfg = Tacotron2Config(speaker_embedding_dim=256)
+    tw = weights.synth_tacotron2(cfg, seed=99)
+    rng = np.random.default_rng(12)
+    N, Tin, T = 32, 64, 12
+    lens = rng.integers(20, 61, N)
+    tok = np.zeros((N, Tin), np.int32)
+    for i, n in enumerate(lens):
+        tok[i, :n] = rng.integers(1, 148, n)
+    spk = rng.standard_normal((N, 256)).astype(np.float32)
+    spk /= np.linalg.norm(spk, axis=1, keepdims=True)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ['MASTER_PORT'] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    eng = _engine(tw, wg_weights)
+    try:
+        pipe = TTSPipeline(eng)
+        kw = dict(max_length=T, deterministic=True, early_stopping=False)
+        audios = synthesize_sharded(tok, pipe.shard_fn(**kw), speaker=spk)
+        assert eng.last_decoder_mode == 'graph'                      # 32 rows: above the fused step's 8
+        assert len(audios) == N and all(a.shape == (T * 256,) for a in audios)
+        order = partition(lens.tolist(), 1)[0]
+        for k in range(0, N, 8):
+            idx = order[k:k + 8]
+            part, n_frames, _ = pipe.synthesize_tokens(tok[idx], speaker=spk[idx], **kw)
+            assert eng.last_decoder_mode == 'fused' and n_frames.tolist() == [T] * 8
+            for row, i in enumerate(idx):
+                assert rms(part[row] - audios[i]) <= WAVE_RMS_TOL, (k, row)
+    finally:
+        dist.destroy_process_group()
+        eng.close()
+    pair = [0, 17]
+    ref = tacotron2_ref.infer(tok[pair], tw, cfg, speaker_embedding=spk[pair], max_length=T, early_stopping=False)
+    ref_audio = waveglow_ref.infer(ref.mel, wg_weights, wg_cfg, z=None)
+    for row, i in enumerate(pair):
+        e = rms(audios[i] - ref_audio[row])
+        print(f'config 4, batch 32: utterance {i} waveform RMS err vs oracle {e:.2e}')
+        assert e <= WAVE_RMS_TOL
+
+
 # ---------------------------------------------------------------------------------------------------------- configs[0]
 def test_config1_single_100_char_sentence_through_tts(gpu_engine, taco_weights, taco_cfg, wg_weights, wg_cfg):
     """The plumbing case: one ~100-character English sentence through `tts()` at batch 1 (cleaners -> ids -> Tacotron2
