@@ -226,15 +226,19 @@ def main():
         print(name, os.path.getsize(os.path.join(HERE, name)))
 
 
-def write_full_size(out_dir, walk=False):
-    """Full-size Tacotron2 checkpoint (seeded synthetic weights) in the Keras layout + the same tensors as .npz: used by the
-    GPU test of `pretrained.load_model` (tests/test_pretrained_gpu.py), which runs this file with the h5py interpreter."""
+def write_full_size(out_dir, walk=False, model='tacotron2', vocab=148, speaker_dim=0):
+    """Full-size checkpoint (seeded synthetic weights) in the Keras layout + the same tensors as .npz: used by the GPU tests of
+    `pretrained.load_model` (tests/test_pretrained_gpu.py), which run this file with the h5py interpreter."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
-    from text_to_speech_amd.config import Tacotron2Config
-    from text_to_speech_amd.weights import synth_tacotron2
-    w = synth_tacotron2(Tacotron2Config(), seed=4321)
-    table = keras_tacotron2_paths(walk)
+    from text_to_speech_amd.config import Tacotron2Config, WaveGlowConfig
+    from text_to_speech_amd.weights import synth_tacotron2, synth_waveglow
+    if model == 'tacotron2':
+        w = synth_tacotron2(Tacotron2Config(vocab_size=vocab, speaker_embedding_dim=speaker_dim), seed=4321)
+        table = keras_tacotron2_paths(walk)
+    else:
+        w = synth_waveglow(WaveGlowConfig(), seed=4321)
+        table = keras_waveglow_paths(walk, n_flows=12, n_layers=8)
     assert sorted(table) == sorted(w)
     os.makedirs(out_dir, exist_ok=True)
     with h5py.File(os.path.join(out_dir, 'ckpt-0000.weights.h5'), 'w') as f:
@@ -245,7 +249,9 @@ def write_full_size(out_dir, walk=False):
 
 if __name__ == '__main__':
     import sys
-    if len(sys.argv) >= 3 and sys.argv[1] == '--full-tacotron2':
-        write_full_size(sys.argv[2], walk=len(sys.argv) > 3 and sys.argv[3] == 'walk')
+    if len(sys.argv) >= 3 and sys.argv[1] in ('--full-tacotron2', '--full-waveglow'):
+        rest = sys.argv[3:]
+        vocab = int(rest[rest.index('--vocab') + 1]) if '--vocab' in rest else 148
+        write_full_size(sys.argv[2], walk='walk' in rest, model=sys.argv[1][len('--full-'):], vocab=vocab)
     else:
         main()

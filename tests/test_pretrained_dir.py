@@ -91,3 +91,56 @@ def test_foreign_directories_are_refused(tmp_path):
     d = make_dir(tmp_path, 'Whisper', 'keras_waveglow_attrs.weights.h5')
     with pytest.raises(ValueError, match='not a model of the TTS path'):
         pretrained.read_model_dir(str(d))
+
+
+def test_architecture_hyper_parameters_and_mel_front_end_are_checked(tmp_path):
+    """`saving/config_models.json` (base_model.py:739-749) and `saving/mel_fn.json` (base_audio_model.py:99,208-217): a
+    checkpoint built with hyper-parameters the engine does not implement is refused by name, not by a shape accident."""
+    d = make_dir(tmp_path, 'Tacotron2', 'keras_tacotron2_walk.weights.h5')
+    save = d / 'saving'
+    ok = {'module': 'architectures.tacotron2_arch', 'class_name': 'Tacotron2', 'registered_name': 'tacotron2>Tacotron2',
+          'config': {'vocab_size': 70, 'n_frames_per_step': 1, 'decoder_n_lstm': 1, 'pred_stop_on_mel': False,
+                     'prenet_sizes': [256, 256], 'encoder_epsilon': 1e-5, 'lsa_attention_dim': 128, 'name': 'tacotron2'}}
+    (save / 'config_models.json').write_text(json.dumps({'model': ok}))
+    (save / 'mel_fn.json').write_text(json.dumps({'class_name': 'TacotronSTFT', 'sampling_rate': 22050, 'n_mel_channels': 80,
+                                                  'filter_length': 1024, 'hop_length': 256, 'win_length': 1024,
+                                                  'mel_fmin': 0.0, 'mel_fmax': 8000.0, 'pre_emph': 0.0, 'window': 'hann'}))
+    info = pretrained.read_model_dir(str(d))
+    assert info['vocab_size'] == 70 and info['hparams']['vocab_size'] == 70 and info['mel_fn']['hop_length'] == 256
+    for key, value in (('n_frames_per_step', 2), ('decoder_n_lstm', 2), ('pred_stop_on_mel', True), ('encoder_epsilon', 1e-3),
+                       ('prenet_sizes', [256, 128]), ('speaker_concat_pos', 'start')):
+        bad = json.loads(json.dumps(ok))
+        bad['config'][key] = value
+        (save / 'config_models.json').write_text(json.dumps({'model': bad}))
+        with pytest.raises(ValueError, match=key):
+            pretrained.read_model_dir(str(d))
+    (save / 'config_models.json').write_text(json.dumps({'model': ok}))
+    (save / 'mel_fn.json').write_text(json.dumps({'class_name': 'TacotronSTFT', 'hop_length': 275, 'mel_fmax': 11025.0}))
+    with pytest.raises(ValueError, match='hop_length'):
+        pretrained.read_model_dir(str(d))
+    (save / 'mel_fn.json').unlink()
+    wg = make_dir(tmp_path, 'WaveGlow', 'keras_waveglow_walk.weights.h5')
+    (wg / 'saving' / 'config_models.json').write_text(json.dumps({'model': {'class_name': 'WaveGlow', 'config': {'n_flows': 6}}}))
+    with pytest.raises(ValueError, match='n_flows'):
+        pretrained.read_model_dir(str(wg))
+
+
+def test_vocabulary_size_comes_from_the_model_directory(tmp_path):
+    """The embedding table has one row per symbol of the model's own tokenizer (the French table has 70, round-2 advisor
+    finding): the manifest the checkpoint is converted against must use that count, and a tokenizer whose padding symbol is
+    not id 0 is refused (the engine masks on token != 0)."""
+    from text_to_speech_amd.text import CharTokenizer
+    d = make_dir(tmp_path, 'Tacotron2', 'keras_tacotron2_walk.weights.h5')
+    tokenizer = CharTokenizer('fr')
+    tokenizer.save(str(d / 'saving' / 'tokenizer.json'))
+    info = pretrained.read_model_dir(str(d))
+    assert info['vocab_size'] == tokenizer.vocab_size == 70
+    cfg = tokenizer.get_config()
+    cfg['vocab'] = cfg['vocab'][1:] + cfg['vocab'][:1]               # the padding symbol moved to the end
+    (d / 'saving' / 'tokenizer.json').write_text(json.dumps(cfg))
+    with pytest.raises(ValueError, match='padding token'):
+        pretrained.read_model_dir(str(d))
+    tokenizer.save(str(d / 'saving' / 'tokenizer.json'))
+    (d / 'saving' / 'config_models.json').write_text(json.dumps({'model': {'class_name': 'Tacotron2', 'config': {'vocab_size': 64}}}))
+    with pytest.raises(ValueError, match='embedding rows'):
+        pretrained.read_model_dir(str(d))

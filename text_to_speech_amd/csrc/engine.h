@@ -114,7 +114,8 @@ struct DecGraphKey {
 struct Tacotron2Dev {
     bool ready = false;
     int enc_dim = 512, spk_dim = 0;
-    float* embeddings = nullptr;        // [148][512]
+    int vocab = 148;                    // rows of the embedding table (the checkpoint's vocabulary)
+    float* embeddings = nullptr;        // [vocab][512]
     ConvBnDev enc_conv[3];
     float* bl_in_Bt[2] = {nullptr, nullptr};   // BiLSTM input kernels [1024][512]
     float* bl_in_b[2] = {nullptr, nullptr};    // [1024]

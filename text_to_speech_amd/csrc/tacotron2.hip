@@ -1011,7 +1011,14 @@ int tacotron2_finalize(tts_hip_engine* e) {
                        dims_str(std::vector<int64_t>{__VA_ARGS__}).c_str());                \
     }
 #define TCHK(x) if ((rc = (x))) { tacotron2_free(e); return rc; }
-    NEED(emb, "encoder/embeddings", 148, 512);
+    // the vocabulary is the checkpoint's: 148 symbols for the reference's English models, 70 for the French table, ...
+    const HostTensor* emb = get("encoder/embeddings");
+    if (!emb) { tacotron2_free(e); return set_err(e, TTS_HIP_ENOTREADY, "missing tensor tacotron2/encoder/embeddings"); }
+    if (emb->dims.size() != 2 || emb->dims[0] < 2 || emb->dims[0] > (1 << 20) || emb->dims[1] != 512) {
+        tacotron2_free(e);
+        return set_err(e, TTS_HIP_EINVAL, "tacotron2/encoder/embeddings has shape %s, expected [vocab >= 2, 512]", dims_str(emb->dims).c_str());
+    }
+    tc.vocab = (int)emb->dims[0];
     TCHK(upload(e, emb->data.data(), emb->numel(), &tc.embeddings, al));
     for (int i = 0; i < 3; ++i) {
         const std::string s = std::to_string(i + 1);
@@ -1235,7 +1242,7 @@ static int tacotron2_encode_impl(tts_hip_engine* e, const int32_t* tokens, int B
     HIPCHK(e, hipMemsetAsync(d_blh, 0, (size_t)2 * B * 2 * 256 * 8, st));
     HIPCHK(e, hipMemsetAsync(out->bl_err, 0, 16 * 4, st));
 
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)R), dim3(128), 0, st, d_tok, tc.embeddings, d_x0, d_mask, (int)R, 148);
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)R), dim3(128), 0, st, d_tok, tc.embeddings, d_x0, d_mask, (int)R, tc.vocab);
     HIPCHK(e, hipGetLastError());
     hipLaunchKernelGGL(enc_len_kernel, dim3(B), dim3(64), 0, st, d_mask, d_enc_len, Tin);
     int rc;

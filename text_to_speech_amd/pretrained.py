@@ -62,6 +62,85 @@ def find_checkpoint(save_dir):
     raise FileNotFoundError(f'no Keras checkpoint (*.weights.h5) in {save_dir}')
 
 
+# What the engine implements of the reference's hyper-parameters (architectures/tacotron2_arch.py:59-135,
+# layers/location_sensitive_attention.py:17-24, waveglow_arch.py:164-178, utils/audio/stft.py:27-60,286-305).  A checkpoint
+# trained with anything else has tensors of other shapes or another graph: it is refused here, by name, instead of being
+# caught (or not) where a tensor shape happens to differ.
+_TACOTRON2_REQUIRED = {
+    'n_mel_channels': 80, 'n_frames_per_step': 1, 'pred_stop_on_mel': False, 'with_logits': True,
+    'attention_rnn_dim': 1024, 'decoder_rnn_dim': 1024, 'decoder_n_lstm': 1,
+    'prenet_sizes': [256, 256], 'prenet_use_bias': False, 'prenet_activation': 'relu', 'prenet_concat_speaker': False,
+    'lsa_attention_dim': 128, 'lsa_attention_filters': 32, 'lsa_attention_kernel_size': 31,
+    'lsa_probability_function': 'softmax', 'lsa_cumulative': True,
+    'encoder_embedding_dim': 512, 'encoder_n_conv': 3, 'encoder_kernel_size': 5, 'encoder_bnorm': 'after',
+    'encoder_activation': 'relu', 'encoder_concat_mode': 'concat', 'encoder_linear_projection': False, 'encoder_pad_token': 0,
+    'postnet_n_conv': 5, 'postnet_filters': 512, 'postnet_kernel_size': 5, 'postnet_bnorm': 'after',
+    'postnet_activation': 'tanh', 'postnet_final_activation': None, 'postnet_linear_projection': False,
+    'speaker_concat_pos': 'end',
+}
+_TACOTRON2_EPS = ('encoder_epsilon', 'postnet_epsilon')          # batch-norm epsilon 1e-5 is folded into the conv weights
+_WAVEGLOW_REQUIRED = {'n_mel_channels': 80, 'n_flows': 12, 'n_group': 8, 'n_early_every': 4, 'n_early_size': 2,
+                      'n_layers': 8, 'n_channels': 512, 'kernel_size': 3}
+_MEL_FN_REQUIRED = {'class_name': 'TacotronSTFT', 'sampling_rate': 22050, 'n_mel_channels': 80, 'filter_length': 1024,
+                    'hop_length': 256, 'win_length': 1024, 'mel_fmin': 0.0, 'mel_fmax': 8000.0}
+
+
+def _same(a, b):
+    if isinstance(b, float) or isinstance(a, float):
+        try:
+            return abs(float(a) - float(b)) <= 1e-9 * max(1.0, abs(float(b)))
+        except (TypeError, ValueError):
+            return False
+    if isinstance(b, list):
+        return isinstance(a, (list, tuple)) and list(a) == b
+    return a == b
+
+
+def check_hparams(model, hparams, where='config_models.json'):
+    """Raises ValueError naming every hyper-parameter of `hparams` (the architecture's `get_config()`) the engine does not
+    implement; absent keys mean the reference's defaults, which are the supported values."""
+    required = _TACOTRON2_REQUIRED if model == 'tacotron2' else _WAVEGLOW_REQUIRED
+    bad = [f'{k} = {hparams[k]!r} (supported: {v!r})' for k, v in required.items() if k in hparams and not _same(hparams[k], v)]
+    if model == 'tacotron2':
+        bad += [f'{k} = {hparams[k]!r} (supported: 1e-05)' for k in _TACOTRON2_EPS if k in hparams and not _same(hparams[k], 1e-5)]
+        n_spk = hparams.get('encoder_n_speaker', 1)
+        if n_spk not in (None, 1):
+            bad.append(f'encoder_n_speaker = {n_spk!r} (supported: 1; speaker identity comes in as an embedding)')
+    if bad:
+        raise ValueError(f'{where}: this checkpoint was built with hyper-parameters the HIP engine does not implement:\n  '
+                         + '\n  '.join(bad))
+
+
+def read_hparams(save_dir, model):
+    """The architecture's hyper-parameters from `saving/config_models.json` (base_model.py:739-749: `{'model':
+    keras.saving.serialize_keras_object(self.model)}`, whose 'config' is `Tacotron2.get_config()` = the HParams,
+    tacotron2_arch.py:927-928 / `WaveGlow.get_config()`, waveglow_arch.py:312-324); {} when the file is absent."""
+    top = _load_json(os.path.join(save_dir, 'config_models.json'))
+    if not top:
+        return {}
+    node = top.get('model', top)
+    hp = node.get('config', {}) if isinstance(node, dict) else {}
+    hp = hp if isinstance(hp, dict) else {}
+    check_hparams(model, hp, os.path.join(save_dir, 'config_models.json'))
+    return hp
+
+
+def check_mel_fn(path):
+    """`saving/mel_fn.json` (base_audio_model.py:99,208-217: `MelSTFT.get_config()`): the analysis the model was trained on
+    must be the TacotronSTFT the engine's mel-STFT implements."""
+    cfg = _load_json(path)
+    if not cfg:
+        return None
+    bad = [f'{k} = {cfg[k]!r} (supported: {v!r})' for k, v in _MEL_FN_REQUIRED.items() if k in cfg and not _same(cfg[k], v)]
+    if cfg.get('pre_emph') not in (None, 0, 0.0, False):
+        bad.append(f"pre_emph = {cfg['pre_emph']!r} (supported: 0)")
+    if cfg.get('window', 'hann') != 'hann':
+        bad.append(f"window = {cfg['window']!r} (supported: 'hann')")
+    if bad:
+        raise ValueError(f'{path}: mel front-end the HIP engine does not implement:\n  ' + '\n  '.join(bad))
+    return cfg
+
+
 def read_model_dir(model_dir):
     """{'class_name', 'config', 'model' ('tacotron2' | 'waveglow'), 'checkpoint', 'tokenizer_file', 'embeddings_dir', 'lang',
     'speaker_embedding_dim'} of a reference model directory."""
@@ -87,9 +166,33 @@ def read_model_dir(model_dir):
                 break
     emb_dir = os.path.join(model_dir, 'embeddings')
     spk = int(cfg.get('embedding_dim', 256 if name == 'SV2TTSTacotron2' else 0) or 0) if name == 'SV2TTSTacotron2' else 0
+    hparams = read_hparams(save_dir, model)
+    mel_fn = check_mel_fn(os.path.join(save_dir, 'mel_fn.json'))
+    vocab_size = None
+    if model == 'tacotron2':
+        # the embedding table has one row per symbol of the model's own tokenizer: the architecture's hyper-parameters say how
+        # many (`vocab_size`), else the wrapper's config, else the tokenizer file (vocabulary + the special tokens in use)
+        for src in (hparams.get('vocab_size'), cfg.get('vocab_size')):
+            if isinstance(src, int) and src > 1:
+                vocab_size = src
+                break
+        if tok_file is not None:
+            from .text import CharTokenizer
+            tokenizer = CharTokenizer.load_from_file(tok_file)
+            if tokenizer.blank_token_idx != 0:
+                raise ValueError(f'{tok_file}: the padding token has id {tokenizer.blank_token_idx}; the engine masks on token '
+                                 f'!= 0 (encoder pad_token = 0, tacotron2_arch.py:62)')
+            if vocab_size is None:
+                vocab_size = tokenizer.vocab_size
+            elif tokenizer.vocab_size > vocab_size:
+                raise ValueError(f'{tok_file}: {tokenizer.vocab_size} symbols but the model has {vocab_size} embedding rows')
+        if hparams.get('encoder_speaker_embedding_dim') not in (None, 0) and spk and int(hparams['encoder_speaker_embedding_dim']) != spk:
+            raise ValueError(f"speaker embedding width: config.json says {spk}, config_models.json says "
+                             f"{hparams['encoder_speaker_embedding_dim']}")
     return {'class_name': name, 'config': cfg, 'model': model, 'checkpoint': find_checkpoint(save_dir),
             'tokenizer_file': tok_file, 'embeddings_dir': emb_dir if os.path.isdir(emb_dir) else None,
-            'lang': cfg.get('lang', 'en'), 'speaker_embedding_dim': spk}
+            'lang': cfg.get('lang', 'en'), 'speaker_embedding_dim': spk, 'hparams': hparams, 'mel_fn': mel_fn,
+            'vocab_size': vocab_size if vocab_size is not None else (148 if model == 'tacotron2' else None)}
 
 
 def convert_model_dir(model_dir, out=None, cfg=None, force=False):
@@ -105,12 +208,20 @@ def convert_model_dir(model_dir, out=None, cfg=None, force=False):
     out = out or ckpt[:-len('.weights.h5')] + '.ttsw'
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(ckpt):
         if cfg is None:
-            cfg = Tacotron2Config(speaker_embedding_dim=info['speaker_embedding_dim']) if info['model'] == 'tacotron2' \
-                else WaveGlowConfig()
+            cfg = Tacotron2Config(speaker_embedding_dim=info['speaker_embedding_dim'], vocab_size=info['vocab_size']) \
+                if info['model'] == 'tacotron2' else WaveGlowConfig()
         tensors = from_keras_h5(ckpt, info['model'], cfg)
-        tmp = out + '.tmp'
-        save_ttsw(tmp, tensors)
-        os.replace(tmp, out)
+        # several ranks / processes may open a fresh directory at once: each writes its own temporary file and publishes it
+        # atomically (a shared name let one writer truncate the file another had just finished)
+        import tempfile
+        fd, tmp = tempfile.mkstemp(prefix=os.path.basename(out) + '.', suffix='.tmp', dir=os.path.dirname(out) or '.')
+        os.close(fd)
+        try:
+            save_ttsw(tmp, tensors)
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
         logger.info('converted %s -> %s (%d tensors)', ckpt, out, len(tensors))
     return out, info
 

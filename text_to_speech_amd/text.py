@@ -648,6 +648,12 @@ class CharTokenizer:
     def vocab_size(self):
         return len(self.symbols)
 
+    @property
+    def blank_token_idx(self):
+        """Id of the padding symbol (utils/text/tokenizer.py `blank_token_idx`); the encoder masks on this id (0 in every
+        symbol table of the TTS models: '_' comes first)."""
+        return self.index.get(self.pad_token, 0)
+
     def clean_text(self, text, **kwargs):
         allowed = ('to_lowercase', 'to_expand', 'to_expand_abrev', 'to_expand_symbols', 'to_expand_acronyms',
                    'replacements', 'patterns', 'max_repetition', 'convert_to_ascii')
