@@ -153,6 +153,11 @@ int tts_hip_tacotron2_decode_seeded(tts_hip_engine* e, const tts_hip_encoded* en
                                     uint64_t seed, uint64_t offset, int win_len, int win_offset, int precision,
                                     float* mel, float* decoder_output, float* stop_tokens, float* attention,
                                     int32_t* lengths, int32_t* steps_run, int mem, void* stream);
+/* Runs the encoder for another token batch INTO an existing encoded batch (its device buffer is reused and only grows):
+ * what a caller that synthesizes sentence after sentence wants -- no hipMalloc / hipFree per sentence, and the decoder's
+ * cached step graphs (keyed by the buffer) survive from one sentence to the next.  Asynchronous like `encode`.        */
+int tts_hip_tacotron2_reencode(tts_hip_engine* e, tts_hip_encoded* encoded, const int32_t* tokens, int B, int Tin,
+                               const float* speaker, int mem, void* stream);
 int tts_hip_encoded_free(tts_hip_engine* e, tts_hip_encoded* encoded);
 
 /* How the autoregressive loop (tacotron2_arch.py:710-735, K.while_loop) is executed.  mode 1: one persistent,

@@ -194,3 +194,24 @@ def test_prenet_masks_drawn_on_the_device(gpu_engine, taco_weights, taco_cfg):
     second = rt(tok, max_length=T, early_stopping=False)                   # a retry: same encoder output, other masks
     assert rt.encoder_reuses >= 1 and not np.array_equal(first.mel, second.mel)
     assert np.array_equal(rt(tok, max_length=T, early_stopping=False, seed=41).mel, first.mel)
+
+
+def test_runtime_reuses_one_encoded_batch_handle_across_sentences(gpu_engine, taco_weights, taco_cfg):
+    """Sentence after sentence through `HipRuntime`: the encoder writes into the SAME encoded-batch buffer
+    (tts_hip_tacotron2_reencode), so the per-step graphs cached for a shape are replayed by the next sentence of that shape
+    instead of being dropped with a freed buffer (round-2 advisor finding), and every result still matches the oracle."""
+    from oracle import tacotron2_ref
+    from text_to_speech_amd.runtime import HipRuntime
+    gpu_engine.set_decoder_mode('graph')
+    try:
+        rt = HipRuntime('unused', engine=gpu_engine, model='tacotron2')
+        handles = set()
+        for seed, (B, Tin) in enumerate([(1, 30), (1, 30), (2, 30), (1, 30), (1, 44)]):
+            tok = _tokens(B, Tin, [Tin - 3 * b for b in range(B)], seed=100 + seed)
+            out = rt(tok, max_length=20, early_stopping=False, deterministic=True)
+            ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=20, early_stopping=False)
+            assert np.abs(out.mel - ref.mel).max() <= 1e-3, (seed, B, Tin)
+            handles.add(rt._encoded[1].handle.value)
+        assert len(handles) == 1 and rt.encoder_reuses == 0
+    finally:
+        gpu_engine.set_decoder_mode('auto')

@@ -52,6 +52,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'tts_hip_tacotron2_decode_seeded': (c_int, [c_void_p, c_void_p, c_int, c_int, c_uint64, c_uint64, c_int, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'tts_hip_tacotron2_reencode': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'tts_hip_encoded_free': (c_int, [c_void_p, c_void_p]),
     'tts_hip_kernel_timing': (c_int, [c_void_p, c_int]),
     'tts_hip_kernel_time_us': (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),

@@ -1811,10 +1811,37 @@ extern "C" int tts_hip_tacotron2_decode_seeded(tts_hip_engine* e, const tts_hip_
                                  attention, lengths, steps_run, mem, precision == 1, ms);
 }
 
+// cached decoder graphs whose kernel nodes point into `buf` (the graphs of other encoded batches stay valid)
+static void tacotron2_graphs_drop(tts_hip_engine* e, const void* buf) {
+    auto& tc = e->taco;
+    for (auto it = tc.graphs.begin(); it != tc.graphs.end();) {
+        if (it->first.enc_buf == buf) {
+            (void)hipGraphExecDestroy(it->second);
+            for (auto o = tc.graph_order.begin(); o != tc.graph_order.end();)
+                o = (!(*o < it->first) && !(it->first < *o)) ? tc.graph_order.erase(o) : std::next(o);
+            it = tc.graphs.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+extern "C" int tts_hip_tacotron2_reencode(tts_hip_engine* e, tts_hip_encoded* encoded, const int32_t* tokens, int B, int Tin,
+                                          const float* speaker, int mem, void* stream) {
+    if (!e || !encoded) return TTS_HIP_EINVAL;
+    StreamScope scope(e, stream);
+    const void* before = encoded->buf.p;
+    // (the encoder itself drops every cached graph if the buffer has to grow; a buffer that stays keeps its graphs: the next
+    // sentence of the same shape bucket replays them)
+    const int rc = tacotron2_encode_impl(e, tokens, B, Tin, speaker, mem, encoded);
+    (void)before;
+    return rc;
+}
+
 extern "C" int tts_hip_encoded_free(tts_hip_engine* e, tts_hip_encoded* encoded) {
     if (!e || !encoded) return TTS_HIP_EINVAL;
     (void)hipSetDevice(e->device);
-    tacotron2_graphs_clear(e);                         // a cached graph may still point into this buffer
+    tacotron2_graphs_drop(e, encoded->buf.p);          // only the cached graphs that point into this buffer
     encoded->buf.release();                            // hipFree waits for work that still uses it
     delete encoded;
     return TTS_HIP_OK;

@@ -296,9 +296,11 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ Tacotron2 in two calls
-    def tacotron2_encode(self, tokens, speaker=None, stream=None):
+    def tacotron2_encode(self, tokens, speaker=None, stream=None, into=None):
         """tokens int32 [B, Tin] (+ speaker [B, E]) -> `EncodedBatch` (the encoder's output, kept on the GPU).  Asynchronous:
-        the encoder is only enqueued (on `stream`, a torch.cuda.Stream, or on the engine's own stream)."""
+        the encoder is only enqueued (on `stream`, a torch.cuda.Stream, or on the engine's own stream).  `into`: an
+        `EncodedBatch` of this engine to overwrite (tts_hip_tacotron2_reencode: no allocation, the decoder's cached graphs
+        stay valid); it is returned."""
         dev = _is_torch_cuda(tokens)
         if dev:
             torch = self._torch()
@@ -326,6 +328,13 @@ class HipEngine:
             sp = None
         if tok.ndim != 2:
             raise ValueError(f'tokens must be [B, Tin], got {tuple(tok.shape)}')
+        if into is not None:
+            if into.engine is not self or into.handle is None:
+                raise ValueError('`into` belongs to another engine or was freed')
+            self._check(self._lib.tts_hip_tacotron2_reencode(self._h, into.handle, ptr(tok), int(tok.shape[0]), int(tok.shape[1]),
+                                                             ptr(spk), MEM_DEVICE if dev else MEM_HOST, sp), 'tacotron2_reencode')
+            into.B, into.Tin, into.on_device, into._keep = int(tok.shape[0]), int(tok.shape[1]), dev, (tok, spk)
+            return into
         h = ctypes.c_void_p()
         self._check(self._lib.tts_hip_tacotron2_encode(self._h, ptr(tok), int(tok.shape[0]), int(tok.shape[1]), ptr(spk),
                                                        MEM_DEVICE if dev else MEM_HOST, sp, ctypes.byref(h)),

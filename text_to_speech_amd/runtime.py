@@ -190,8 +190,17 @@ class HipRuntime(Runtime):
                 precision=precision or self.synthesizer_precision)
         if self._encoded is not None and self._encoded[0] == key:
             self.encoder_reuses += 1
+        elif self._encoded is not None:
+            # one encoded-batch handle per runtime, overwritten sentence after sentence: no device allocation per sentence,
+            # and the decoder's cached step graphs (keyed by that buffer) are replayed instead of re-captured
+            handle = self._encoded[1]
+            self._encoded = None
+            try:
+                self._encoded = (key, self.engine.tacotron2_encode(tokens, speaker=speaker, into=handle))
+            except Exception:
+                handle.close()
+                raise
         else:
-            self._drop_encoded()
             self._encoded = (key, self.engine.tacotron2_encode(tokens, speaker=speaker))
         try:
             return self.engine.tacotron2_decode(
