@@ -2,7 +2,8 @@
 
 Same behaviour as /root/reference/models/tts/waveglow.py:61-142 (`infer`: path / 2-D / 3-D mel input, `audio_len = T * 256`,
 optional pad-to-`win_len` with -11, window / hop chunking with centre-half stitching) and :156-164 (`_get_steps`),
-pinned by the known-answer tests in tests/test_host_logic.py.
+pinned by outputs of the reference's own `_get_steps` and stitch statements (tests/golden/host_vectors.json,
+tests/test_host_vectors.py) and the known-answer tests in tests/test_host_logic.py.
 The compute call (`self.compiled_infer`) is a `HipRuntime`; nothing here touches a CPU fallback.
 """
 from __future__ import annotations
@@ -151,7 +152,13 @@ class WaveGlow:
         shared = (starts[:-1] + win_len - starts[1:]) * 256
         head = np.concatenate([[0], shared // 2])
         tail = np.concatenate([-(-shared // 2), [0]])            # the reference slices `[: -overlap // 2]` = ceil half
-        return np.concatenate([p[h:len(p) - t] for p, h, t in zip(pieces, head, tail)], axis=-1)
+        last = len(pieces) - 1
+        # (sic) a window that shares NO frame with its successor (hop_len == win_len) is sliced `part[start : -0 // 2]` =
+        # `part[start : 0]` by the reference (models/tts/waveglow.py:136-139): empty.  Kept, because the contract here is the
+        # reference's output on the same arguments (pinned by tests/golden/host_vectors.json); overlapping windows -- every
+        # default -- are seamless.
+        ends = [len(p) - t if (i == last or t > 0) else 0 for i, (p, t) in enumerate(zip(pieces, tail))]
+        return np.concatenate([p[h:e] for p, h, e in zip(pieces, head, ends)], axis=-1)
 
     __call__ = infer
 
