@@ -31,11 +31,10 @@ def copy_stats(sub, name):
 copy_stats('stats', f'{tag}_bench_kernel_stats.csv')
 copy_stats('stats_f16', f'{tag}_waveglow_f16_kernel_stats.csv')
 copy_stats('stats_f16x3', f'{tag}_waveglow_f16x3_kernel_stats.csv')
-for b in (1, 8):
-    copy_stats(f'taco_b{b}', f'{tag}_tacotron2_b{b}_kernel_stats.csv')
-copy_stats('taco_b1_persistent', f'{tag}_tacotron2_b1_persistent_kernel_stats.csv')
-copy_stats('taco_b8_persistent', f'{tag}_tacotron2_b8_graph_kernel_stats.csv')        # batch 8 falls back to the per-step graph
-copy_stats('taco_b1_graph', f'{tag}_tacotron2_b1_graph_kernel_stats.csv')
+for sub in sorted(glob.glob(os.path.join(src, 'taco_b*'))):
+    name = os.path.basename(sub)
+    if os.path.isdir(sub) and not name.startswith('taco_pmc'):
+        copy_stats(name, f'{tag}_tacotron2_{name[len("taco_"):]}_kernel_stats.csv')
 bj = os.path.join(src, 'bench_under_rocprof.json')
 if os.path.exists(bj):
     lines = [l for l in open(bj) if l.startswith('{')]
@@ -78,12 +77,14 @@ for kn, cs in merged.items():
     if 'SQ_WAIT_ANY' in cs and 'SQ_WAVE_CYCLES' in cs:
         e['wait_any_frac'] = sum(cs['SQ_WAIT_ANY']) / max(1.0, sum(cs['SQ_WAVE_CYCLES']))
     summary['kernels'][kn[:120]] = e
-for b in (1, 8):
-    taco = counters(f'taco_pmc_b{b}')
+for sub in sorted(glob.glob(os.path.join(src, 'taco_pmc_b*'))):
+    if not os.path.isdir(sub):
+        continue
+    taco = counters(os.path.basename(sub))
     if taco:
-        summary[f'tacotron2_b{b}_fetch_KB_mean'] = {
+        summary['tacotron2_' + os.path.basename(sub)[len('taco_pmc_'):] + '_fetch_KB_mean'] = {
             kn[:90]: {'mean_KB': sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE']), 'launches': len(cs['FETCH_SIZE'])}
-            for kn, cs in taco.items() if 'FETCH_SIZE' in cs and ('persist' in kn or len(cs['FETCH_SIZE']) >= 32)}
+            for kn, cs in taco.items() if 'FETCH_SIZE' in cs and ('persist' in kn or 'fused' in kn or len(cs['FETCH_SIZE']) >= 32)}
 # fp16 / split-fp16 WaveGlow kernels: bytes, MFMA busy fraction and effective clock of every GEMM / end-fold kernel
 for prec in ('f16', 'f16x3'):
     m = {}
