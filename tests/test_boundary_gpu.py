@@ -215,3 +215,38 @@ def test_runtime_reuses_one_encoded_batch_handle_across_sentences(gpu_engine, ta
         assert len(handles) == 1 and rt.encoder_reuses == 0
     finally:
         gpu_engine.set_decoder_mode('auto')
+
+
+def test_two_handles_on_the_fused_step_take_turns(gpu_engine, taco_weights):
+    """The fused two-kernel step needs every CU at once, like the persistent kernel: two handles of one process decoding at the
+    same time are serialised by a per-device lock inside the library (two half-resident grids would wait for each other until
+    their bounded waits give up and both calls fall back).  Both calls must stay on the fused step and equal their solo runs."""
+    import threading
+    from text_to_speech_amd.engine import HipEngine
+    eng2 = HipEngine(0)
+    eng2.load_state(taco_weights)
+    eng2.finalize()
+    try:
+        engines = [gpu_engine, eng2]
+        for e in engines:
+            e.set_decoder_mode('fused')
+        toks = [_tokens(4, 60, [60, 50, 33, 60], seed=31), _tokens(6, 45, [45, 30, 45, 12, 40, 45], seed=32)]
+        alone = [e.tacotron2_infer(t, max_len=200, early_stopping=False, want_attention=False) for e, t in zip(engines, toks)]
+        for _ in range(3):
+            res, modes = [None, None], [None, None]
+
+            def run(i):
+                res[i] = engines[i].tacotron2_infer(toks[i], max_len=200, early_stopping=False, want_attention=False)
+                modes[i] = engines[i].last_decoder_mode
+
+            th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert modes == ['fused', 'fused'], modes
+            for i in range(2):
+                assert np.array_equal(res[i].mel, alone[i].mel) and np.array_equal(res[i].lengths, alone[i].lengths)
+    finally:
+        gpu_engine.set_decoder_mode('auto')
+        eng2.close()

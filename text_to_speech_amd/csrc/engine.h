@@ -135,6 +135,8 @@ struct Tacotron2Dev {
                                         // two-kernel step when allowed, 3 auto (persistent for 1 - 2 rows, fused above)
     int last_path = -1;                 // how the last call ran its loop: 2 fused step, 1 persistent kernel, 0 per-step graph
     bool persist_timed = true;          // persistent kernel: timed optimistic polls on (switched off if they mostly miss)
+    int fused_backoff = 0;              // calls to keep off the fused step after one of its exchanges timed out (shared GPU)
+    int fused_fail_streak = 0;
     ConvBnDev post_conv[5];
     std::vector<void*> allocs;
     DevBuf ws;                          // per-call workspace arena

@@ -20,6 +20,7 @@
 #include "taco_fused.h"
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 #include "gemm_f32.h"
 
@@ -1296,6 +1297,11 @@ static int tacotron2_encode_impl(tts_hip_engine* e, const int32_t* tokens, int B
     return TTS_HIP_OK;
 }
 
+static std::mutex& whole_gpu_mutex(int device) {
+    static std::mutex m[PerDeviceOnce::kMaxDevices];
+    return m[device >= 0 && device < PerDeviceOnce::kMaxDevices ? device : 0];
+}
+
 // ---------------------------------------------------------------------------------------------------------- decoder
 // Autoregressive loop + postnet from an encoded batch.  Enqueued on e->stream; synchronizes it before returning (the
 // loop's exit is data dependent and `steps_run` / the BiLSTM status are host values).
@@ -1534,6 +1540,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
     };
     int bl_err = 0;
     bool bl_checked = false;
+    bool try_fused_now = try_fused;
     if (try_persist) {
         // Persistent weight-stationary loop (taco_persist.hip): the attention context is folded through the four linear maps
         // that consume it -- PM = memory x [W_att[:, ctx] | W_dec[:, ctx] | F[:, ctx] | P[:, ctx]] -- once per utterance.
@@ -1563,7 +1570,12 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         pc.memory = d_memory; pc.pm = d_pm; pc.mask = d_mask; pc.enc_len = d_enc_len; pc.masks = masks_dev;
         pc.pm_fold = d_pmfold; pc.xch = d_xch; pc.flags = d_pflags;
         pc.dec_out = d_decout; pc.stop_out = d_stop; pc.attn_hist = d_attn; pc.lengths = d_lengths; pc.finished = d_finished;
+        // The persistent kernel and the fused step each need every CU of the device at once: two of them from two handles of
+        // one process would hold half the CUs each and wait for the other half (until their bounded waits give up).  One at a
+        // time per device; the work is the same, and nothing deadlocks.  (Another process is handled by the timeouts.)
+        std::unique_lock<std::mutex> whole_gpu(whole_gpu_mutex(e->device));
         const int prc = persist_decode(e, st, pc, &host_steps);
+        whole_gpu.unlock();
         if (prc < 0) return prc;
         persisted = prc == TTS_HIP_OK;                  // 1: the grid could not become resident -> per-step graph below
         if (prc == 2) {                                 // gave up in mid-loop: start over on the per-step graph
@@ -1572,7 +1584,12 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
             HIPCHK(e, hipGetLastError());
         }
     }
-    if (try_fused) {
+    if (try_fused && tc.fused_backoff > 0) {
+        --tc.fused_backoff;                              // a recent call timed out (the GPU is shared): not this time
+        try_fused_now = false;
+    }
+    if (try_fused_now) {
+        std::unique_lock<std::mutex> whole_gpu(whole_gpu_mutex(e->device));      // see the persistent section above
         // Fused two-kernel step (taco_fused.hip): chunks of FUSED_CHUNK steps, one hipGraph per shape bucket; after each chunk
         // the host reads the loop state (32 bytes) and the abort flag.
         FusedCall fc{};
@@ -1652,7 +1669,12 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
             }
         }
         if (bl_err) return set_err(e, TTS_HIP_EHIP, "tacotron2 encoder: BiLSTM block exchange timed out");
-        if (!fused) {
+        if (fused) {
+            tc.fused_fail_streak = 0;
+        } else {
+            // back off exponentially (1, 2, 4 ... 64 calls on the per-step graph) while another tenant keeps the CUs busy
+            tc.fused_fail_streak = std::min(tc.fused_fail_streak + 1, 7);
+            tc.fused_backoff = 1 << (tc.fused_fail_streak - 1);
             set_err(e, TTS_HIP_EHIP, "tacotron2 fused decoder: an exchange timed out; fell back to the per-step graph");
             if ((rc = zero_state())) return rc;
             hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, d_state, B, max_len, early_stop ? 1 : 0);
