@@ -24,7 +24,7 @@ assert eng.last_decoder_mode == 'fused'
 tr = np.fromfile(path, dtype=np.int64).reshape(128, 2, 4, 16).astype(np.float64) * 0.01      # us
 xn = {0: 'role entry', 1: 'role DMA staged', 2: 'role past #1', 3: 'p1 out', 4: 'p1 polled, p2 computed', 5: 'p2 out', 6: 'p2 quarter polled',
       7: 'role past #2', 8: 'lstm entry', 9: 'lstm past #1', 10: 'lstm early FMAs done', 15: 'p1 dots done',
-      11: 'lstm past #2', 12: 'lstm reduced', 13: 'lstm first slice done', 14: 'lstm end'}
+      11: 'lstm past #2', 12: 'lstm reduced', 13: 'kernel first instruction (role wave 0, block 0)', 14: 'lstm end'}
 yn = {0: 'role entry', 1: 'role DMA staged', 2: 'role past #1', 3: 'q out', 4: 'q polled', 5: 'e out', 6: 'e row polled', 7: 'ctx out',
       8: 'ctx quarter polled', 9: 'role past #2', 10: 'lstm entry', 11: 'lstm past #1', 12: 'lstm early FMAs done',
       15: 'q dots done', 13: 'lstm past #2', 14: 'lstm end'}

@@ -186,27 +186,37 @@ def test_overlapped_stream_keeps_order_overlaps_work_and_propagates_errors():
     from text_to_speech_amd.tacotron2 import Tacotron2
     from text_to_speech_amd.waveglow import WaveGlow
 
+    spans = {'synth': [], 'voc': []}                                  # (start, end) of every call, by stage
+
     class SlowSynth(FakeSynth):
         def __call__(self, inputs, **kw):
+            t = _time.monotonic()
             _time.sleep(0.05)
-            return super().__call__(inputs, **kw)
+            out = super().__call__(inputs, **kw)
+            spans['synth'].append((t, _time.monotonic()))
+            return out
 
     class SlowVocoder(FakeVocoder):
         def __call__(self, mel, **kw):
+            t = _time.monotonic()
             _time.sleep(0.05)
-            return super().__call__(mel, **kw)
+            out = super().__call__(mel, **kw)
+            spans['voc'].append((t, _time.monotonic()))
+            return out
 
     texts = [f'This is sentence number {i} of the stream.' for i in range(8)]
     synth, voc = SlowSynth([], default=120), SlowVocoder()
     model = Tacotron2(synth)
     model.precompile_for_stream = lambda **kw: None                  # keep the timing clean
     got = []
-    t0 = _time.time()
     model.stream(iter(texts), vocoder=WaveGlow(voc), save=False, overlap=True,
                  callbacks=[lambda text, audio, **_: got.append((text, len(audio)))])
-    dt = _time.time() - t0
     assert [g[0] for g in got] == texts and all(n == 120 * 256 for _, n in got)
-    assert dt < 0.7                                                   # sequential would be 8 * 0.10 = 0.8 s
+    # the work overlaps: Tacotron2(n + 1) starts before WaveGlow(n) has ended (judged from the recorded spans, not from a
+    # wall-clock budget, which a loaded machine does not keep)
+    assert len(spans['synth']) == len(spans['voc']) == 8
+    overlapped = sum(spans['synth'][n + 1][0] < spans['voc'][n][1] for n in range(7))
+    assert overlapped >= 6, spans
     # same results as the sequential path
     seq = Tacotron2(SlowSynth([], default=120)).predict(texts[:2], vocoder=WaveGlow(SlowVocoder()), save=False)
     ovl = Tacotron2(SlowSynth([], default=120)).predict(texts[:2], vocoder=WaveGlow(SlowVocoder()), save=False, overlap=True)

@@ -22,7 +22,7 @@
 
 #include "dev_util.h"
 
-// Timing ablations of the fp16 loop (TTS_ABL = 1..6; results are garbage when set) only exist in a build made with
+// Timing ablations of the fp16 loop (TTS_ABL = 1..7; results are garbage when set) only exist in a build made with
 // -DTTS_DEBUG_HOOKS -DTTS_ABL=n; csrc/build.sh never passes either.
 #ifndef TTS_DEBUG_HOOKS
 #undef TTS_ABL
@@ -407,7 +407,12 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                 const bool kok = kci * BK + c4 < kI;
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
-                    const bool ok = kok && ((vmaskI[p] >> si) & 1u);
+                    bool ok = kok && ((vmaskI[p] >> si) & 1u);
+#if TTS_ABL
+                    // ablation 7: the taps of a layer with dilation >= 32 sit in the tile's own phase block -- price what ONE
+                    // shared activation tile per K chunk would save by making the outer taps' stagings fetch nothing
+                    if (HALF && TTS_ABL == 7 && g.phase_step == 1 && si != 1) ok = false;
+#endif
                     emit(true, p, rsI, ok ? baseI[p] + delta : OOB, (unsigned)(sg0.plane * 4));
                 }
                 if (++si == NI) {

@@ -415,6 +415,27 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
     auto ekoff = [](int e) { return e < NC_ ? PRE + e * 256 : PRE + ENC + (e - NC_) * 256; };      // column inside the weight row
     f32x4 hv[NS2];                                    // LSTM waves: this thread's share of h_att(t-1)
     WSlice<HW> win[PF];
+    // role waves: the operands of their roles (rows of the folded prenet-1 / projection / prenet-2 matrices) do not depend on
+    // the loop state either; requested here they have landed when barrier #1 opens (requested behind the state they arrived
+    // 0.4 us after it)
+    constexpr int KP_ = RNN + ENC, NP_ = KP_ / 256;
+    f32x4 R[NP_];
+    float rbias = 0.f;
+    int fin_old = 0;
+    if (wave >= 4) {
+        const int r_ = wave - 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const bool p1w = r_ == 0 || r_ == 3, projw = r_ == 2 && blk <= NMEL;
+#pragma unroll
+        for (int i = 0; i < NP_; ++i) {
+            const float* src = p1w ? a.Ff + (size_t)blk * KP_ + i * 256 + lane * 4
+                             : projw ? a.Pw + (size_t)blk * KP_ + i * 256 + lane * 4
+                             : (r_ == 1 && i == 0) ? a.W1t + (size_t)blk * PRE + lane * 4 : nullptr;
+            R[i] = src ? *reinterpret_cast<const f32x4*>(src) : zero;
+        }
+        rbias = p1w ? a.fb[blk] : projw ? a.Pb[blk] : 0.f;
+        if (projw && blk == NMEL && lane < B) fin_old = a.finished[lane];
+    }
     if (wave < 4) {
         const float* ha = a.hatt + (size_t)par * B * RNN;
 #pragma unroll
@@ -523,21 +544,6 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
     P.abort_s = ctl;
     const bool is_p1 = (r == 0 || r == 3) && step_on, is_p2 = r == 1 && step_on, is_proj = r == 2 && frame_on && blk <= NMEL;
     const int row_lo = r == 3 ? HB : 0;               // first row of a prenet-1 wave
-    f32x4 R[NP];
-    float rbias = 0.f;
-    {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const float* src = is_p1 ? a.Ff + (size_t)blk * KP + i * 256 + lane * 4
-                             : is_proj ? a.Pw + (size_t)blk * KP + i * 256 + lane * 4
-                             : (is_p2 && i == 0) ? a.W1t + (size_t)blk * PRE + lane * 4 : nullptr;
-            R[i] = src ? *reinterpret_cast<const f32x4*>(src) : zero;
-        }
-        rbias = is_p1 ? a.fb[blk] : is_proj ? a.Pb[blk] : 0.f;
-    }
-    int fin_old = 0;
-    if (is_proj && blk == NMEL && lane < B) fin_old = a.finished[lane];
     float dmask = 1.f;                                // prenet dropout mask of (row, output blk); row = row_lo + lane for prenet 1
     {
         const int mrow = is_p1 ? row_lo + lane : lane;
@@ -679,6 +685,13 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     auto ecol = [](int e) { return e < 4 ? e * 256 : RNN + ENC + (e - 4) * 256; };
     f32x4 hv[NS2];                                    // LSTM waves: this thread's share of h_dec(t-1)
     WSlice<HW> win[PF];
+    f32x4 RQ[4];                                      // query wave (role wave 3): its row of the query matrix (see kernel X)
+    {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            RQ[i] = wave == 7 ? *reinterpret_cast<const f32x4*>(a.Wq + (size_t)(blk & (ATT - 1)) * RNN + i * 256 + lane * 4) : zero;
+    }
     if (wave < 4) {
         const float* hd = a.hdec + (size_t)par * B * RNN;
 #pragma unroll
@@ -779,12 +792,6 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     // query: r == 3 of block blk computes attention dim blk & 127 of rows [0, HB) (blk < 128) or [HB, NBT) (blk >= 128)
     const bool is_q = r == 3;
     const int qdim = blk & (ATT - 1), qrow = blk < ATT ? 0 : HB;
-    f32x4 RQ[4];
-    {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) RQ[i] = is_q ? *reinterpret_cast<const f32x4*>(a.Wq + (size_t)qdim * RNN + i * 256 + lane * 4) : zero;
-    }
     const f32x2 vv = *reinterpret_cast<const f32x2*>(a.vw + lane * 2);
     f32x2 pmv[NPOS];
     float cp[NPOS], cc[NPOS];                         // alignment windows: lane i < 31 holds position tau + i - 15
@@ -1143,7 +1150,7 @@ int fused_enqueue_chunk(tts_hip_engine* e, hipStream_t st, const FusedCall& c) {
     a.trace = c.trace;
     // first look at a hop this long after the block's own producer published (10-ns ticks): the latency of a tagged publish
     // under the weight stream; found with scripts/fused_sweep.py.  A wrong value costs time, never correctness.
-    static const int kDelay[5] = {90, 90, 80, 80, 100};
+    static const int kDelay[5] = {90, 90, 115, 115, 100};
     for (int i = 0; i < 5; ++i) a.delay[i] = kDelay[i];
 #ifdef TTS_DEBUG_HOOKS
     if (const char* dl = getenv("TTS_FUSED_DELAYS")) {            // "a,b,c,d,e"

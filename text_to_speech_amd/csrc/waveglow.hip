@@ -867,7 +867,12 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 g.out0h = acts_i;
                 g.ld0h = C;
                 g.planeOut = (long long)M * C;
+#ifdef TTS_DEBUG_HOOKS
+                static const bool split_dil = getenv("TTS_TIME_SPLIT_DIL") != nullptr;    // measurement builds: time the
+                timing_begin(e, i == 0 ? 3 : (split_dil && d >= 32) ? 2 : 0);             // layers with d >= 32 as kind 2
+#else
                 timing_begin(e, i == 0 ? 3 : 0);
+#endif
                 if (x3) HIPCHK(e, i == 0 ? gemm_wn_in0_x3(g, row64, st) : gemm_wn_in_x3(g, row64, st));
                 else if (row64) HIPCHK(e, i == 0 ? gemm_wn_in0_r64h(g, st) : gemm_wn_in_r64h(g, st));
                 else if (tile64) HIPCHK(e, i == 0 ? gemm_wn_in0_64h(g, st) : gemm_wn_in_64h(g, st));
