@@ -19,6 +19,7 @@
 
 #include <atomic>
 #include <stdint.h>
+#include <utility>
 
 #include "dev_util.h"
 
@@ -42,6 +43,10 @@
 #ifndef TTS_LOADER4
 #define TTS_LOADER4 1
 #endif
+// fp32 LDS-DMA kernels: K loop rotated by half a step (see "rotated loop" in the kernel).  0 = the plain loop.
+#ifndef TTS_F32_ROT
+#define TTS_F32_ROT 1
+#endif
 
 namespace ttsgemm {
 
@@ -49,6 +54,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int MAX_SEG = 8;
+
+// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}): a loop whose index is a constant expression in the
+// body (instruction immediates)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 // Row addressing of a segment.  With GemmArgs::phase_rows > 0 the M axis is "phase-major": row m = p * phase_rows + f
 // (p = one of 32 sample-group phases inside a mel frame, f = frame row), which keeps every conv tap a constant row
@@ -178,6 +194,13 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     constexpr int RPP = NT / TPR;           // rows staged per pass of the staging threads
     constexpr int PA = BM / RPP;            // float4 loads per thread for the A tile
     constexpr int PB = BN / RPP;
+    // fp32 LDS-DMA kernels run the rotated K loop (below).  There a wave stages CONTIGUOUS rows -- piece p of wave w covers rows
+    // (w * PA + p) * 16 .. + 15 of the tile instead of p * 64 + w * 16 .. -- so that all pieces of one operand side share ONE
+    // LDS base (one M0 write) and differ in the instruction's immediate offset (p KiB), which the hardware adds to the LDS
+    // address AND to the buffer offset: descriptors are based ROT_SH bytes low and the per-lane offsets carry ROT_SH - p KiB.
+    constexpr bool ROT = DMA && !HALF && PL == 1 && NBD == 3 && BK == 16 && TTS_F32_ROT && (!(TTS_ABL) || TTS_ABL >= 9);
+    constexpr int ROT_SH = ROT ? 3072 : 0;
+    static_assert(!ROT || (PA <= 4 && PB <= 4), "immediate offsets are 12 bits");
     static_assert(WR * WC == 4 || WR * WC == 8, "4 or 8 waves");
     static_assert(BK == 16 || BK == 32, "BK");
 
@@ -222,6 +245,10 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     // k offset of this thread's float4.  DMA: LDS slot (row, c') receives global chunk c' ^ ((row >> 2) & 3)
     //          (H16: c' ^ (-(row >> 2) & 3), the permutation that makes the 16-row x 4-chunk operand reads conflict-free)
     const int c4 = DMA ? (((tid & 3) ^ ((TTS_H16 && HALF ? -(tid >> 4) : (tid >> 4)) & 3)) * 4) : (tid % TPR) * 4;
+    // tile row that piece p of this thread stages (A / B side), and what its per-lane byte offset carries besides the address
+    auto rowA = [&](int p) -> int { return ROT ? (wave * PA + p) * 16 + (lane >> 2) : p * RPP + lrow; };
+    auto rowB = [&](int p) -> int { return ROT ? (wave * PB + p) * 16 + (lane >> 2) : p * RPP + lrow; };
+    auto adj = [&](int p) -> unsigned { return (unsigned)(ROT_SH - (ROT ? p * 1024 : 0)); };
     const int li = lane & 31, lh = lane >> 5;
     // Accumulator register r of a 32 x 32 tile holds (row trow(r), column tcol(r)) of the tile.  32x32 MFMA: column =
     // lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  H16 (four 16x16x32 sub-tiles, registers 4 s .. 4 s + 3 for
@@ -293,7 +320,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     int a_l[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int fr = f0 + p * RPP + lrow;
+        const int fr = f0 + rowA(p);
         const bool ok = PH ? fr < g.frames : fr < g.M;
         a_l[p] = ok ? fr % g.L : -0x40000000;           // padding rows never pass the [0, L) test below
     }
@@ -315,7 +342,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     unsigned b_off[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p)
-        b_off[p] = (n0 + p * RPP + lrow < g.N) ? (unsigned)(((p * RPP + lrow) * (int)g.ldb + c4) * 4) : OOB;
+        b_off[p] = (n0 + rowB(p) < g.N) ? (unsigned)((rowB(p) * (int)g.ldb + c4) * 4) + adj(p) : OOB;
 
     // tile iterator (wave-uniform) over the sequential segments [NI, nseg): current segment parameters live in
     // registers, refreshed only at a crossing
@@ -323,6 +350,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     int seg_k = 0, seg_kpad = 0;
     unsigned seg_plane = 0;                          // byte offset of the current sequential segment's second plane
     __amdgpu_buffer_rsrc_t rsA;
+    const float* ptrSeqA = nullptr;                  // base of rsA (the rotated loop rebuilds descriptors from pointers)
     unsigned a_off[PA];
     auto enter_segment = [&]() {
         const ASeg sg = g.seg[s_cur];
@@ -332,11 +360,12 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         long long abs_row;
         int vshift;
         seg_row(sg, abs_row, vshift);
-        rsA = make_rsrc(sg.ptr + z * g.strideAz + abs_row * sg.ld);
+        ptrSeqA = sg.ptr + z * g.strideAz + abs_row * sg.ld;
+        rsA = make_rsrc(ptrSeqA);
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int l2 = a_l[p] + vshift;
-            a_off[p] = (l2 >= 0 && l2 < g.L) ? (unsigned)(((p * RPP + lrow) * (int)sg.ld + c4) * 4) : OOB;
+            a_off[p] = (l2 >= 0 && l2 < g.L) ? (unsigned)((rowA(p) * (int)sg.ld + c4) * 4) + adj(p) : OOB;
         }
     };
     // second weight matrix (per-phase) for the sequential segments
@@ -346,7 +375,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     unsigned b_off2[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p)
-        b_off2[p] = (n0 + p * RPP + lrow < g.N) ? (unsigned)(((p * RPP + lrow) * (int)g.ldb2 + c4) * 4) : OOB;
+        b_off2[p] = (n0 + rowB(p) < g.N) ? (unsigned)((rowB(p) * (int)g.ldb2 + c4) * 4) + adj(p) : OOB;
 
     // ---- tile fetch: the same address generation feeds either register stages (PIPE_REG) or LDS-DMA (PIPE_DMA);
     // `emit(isA, p, rsrc, voffset)` is the sink.
@@ -362,6 +391,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     // checked at launch) and the validity bits of the staged rows.  Only these survive into the K loop.
     unsigned dl0 = 0, dl1 = 0, dl2 = 0, dl3 = 0;
     __amdgpu_buffer_rsrc_t rsI = rsB;
+    const float* ptrIbase = g.Bt;                    // base of rsI
     unsigned baseI[PA], vmaskI[PA];
     {
         long long ab0 = 0, ab1 = 0, ab2 = 0, ab3 = 0;
@@ -374,7 +404,10 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         row0 = ab1 < row0 ? ab1 : row0;
         row0 = ab2 < row0 ? ab2 : row0;
         row0 = ab3 < row0 ? ab3 : row0;
-        if (NI > 0) rsI = make_rsrc(sg0.ptr + z * g.strideAz + row0 * sg0.ld);
+        if (NI > 0) {
+            ptrIbase = sg0.ptr + z * g.strideAz + row0 * sg0.ld;
+            rsI = make_rsrc(ptrIbase);
+        }
         const int ld4 = (int)sg0.ld * 4;
         dl0 = (unsigned)((int)(ab0 - row0) * ld4);
         dl1 = (unsigned)((int)(ab1 - row0) * ld4);
@@ -383,7 +416,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         auto vs_of = [&](int s2) { return s2 == 0 ? vs0 : s2 == 1 ? vs1 : s2 == 2 ? vs2 : vs3; };
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            baseI[p] = (unsigned)(((p * RPP + lrow) * (int)sg0.ld + c4) * 4);
+            baseI[p] = (unsigned)((rowA(p) * (int)sg0.ld + c4) * 4) + adj(p);
             unsigned vm = 0;
 #pragma unroll
             for (int s = 0; s < NI; ++s) {
@@ -526,6 +559,22 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             return;
         }
         f32x4 fa[RT], fb[CT];
+#if TTS_ABL == 8 && defined(TTS_ABL_F32)
+        if (!HALF) {                                 // ablation 8: the MFMAs of a K step without their operand reads
+#pragma unroll
+            for (int i = 0; i < RT; ++i) fa[i] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(lane + i);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) fb[j] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(lane - j);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
 #if TTS_ABL
@@ -554,7 +603,126 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     };
 
     if (nSeq > 0) enter_segment();
-    if constexpr (DMA) {
+    if constexpr (ROT) {
+        // ---- rotated loop (fp32 LDS-DMA kernels).  Measured on the plain loop below (config 2, 5.69 ms per launch, debug
+        // builds with -DTTS_ABL_F32): without the DMA issue 5.19 ms, without the operand reads 5.54, without wait + barrier 5.60,
+        // DMA + barrier alone 1.22 -- a wave issued its 6 DMA pieces, then its operand reads, and only then had MFMAs to offer.
+        // Here the step boundary sits in the MIDDLE of a tile's MFMAs: a step = [reads of chunk 1 | MFMAs of chunk 0 | wait +
+        // barrier | reads of the NEXT tile's chunk 0 | MFMAs of chunk 1 with the DMA pieces of tile t + 3 issued one per MFMA row
+        // group].  Every operand read has 32 MFMAs (2 048 cycles) to land, a wave leaves the barrier with 32 MFMAs ready, and the
+        // pieces of one operand side share one M0 value.  All three LDS buffers are requested up front; tile t + 3 goes into the
+        // buffer of tile t once every wave has its fragments of tile t in registers (the barrier of step t).  Effect: 5.67 ->
+        // 5.60 ms; what remains of the DMA cost (the same loop without its pieces: 5.23 ms) is ~50 cycles of matrix-pipe time
+        // per piece wherever the piece is placed -- a per-instruction price, so only fewer bytes per MFMA would lower it.
+        constexpr int LT = PA + PB;
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        unsigned vo[LT];                                 // per-lane source offsets of the prepared tile's pieces
+        __amdgpu_buffer_rsrc_t rsTa = rsB, rsTb = rsB;   // its descriptors (A side, B side)
+        auto prepare_next = [&]() {                      // address math of tile `t_load`.  Past the last tile the pieces fetch
+            if (t_load >= nAll) {                        // nothing (all lanes out of range: zeros into a buffer nobody reads
+#pragma unroll                                           // again), so that the loop body and its counted waits are uniform
+                for (int q = 0; q < LT; ++q) vo[q] = OOB;
+                return;
+            }
+            const bool inter = NI > 0 && t_load < nI;
+            if (inter) {
+                const unsigned delta = delta_of(si) + (unsigned)(kci * BK * 4);
+                const bool kok = kci * BK + c4 < kI;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const bool ok = kok && ((vmaskI[p] >> si) & 1u);
+                    vo[p] = ok ? baseI[p] + delta : OOB;
+                }
+                if (++si == NI) {
+                    si = 0;
+                    ++kci;
+                }
+                rsTa = make_rsrc_uniform(ptrIbase - ROT_SH / 4);
+            } else {
+                const unsigned kb = (unsigned)(kc_cur * BK * 4);
+                const bool kok = kc_cur * BK + c4 < seg_k;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) vo[p] = kok ? a_off[p] + kb : OOB;
+                rsTa = make_rsrc_uniform(ptrSeqA - ROT_SH / 4);
+                if (++kc_cur * BK >= seg_kpad) {
+                    kc_cur = 0;
+                    if (++s_cur < g.nseg) enter_segment();      // (rsA changes for the NEXT tile; rsTa keeps this tile's copy)
+                }
+            }
+            const bool use2 = B2 && !inter;
+            rsTb = make_rsrc_uniform((use2 ? bbase2 : bbase1) - ROT_SH / 4);
+            const unsigned kg = (unsigned)((use2 ? kglob2 : kglob) * 4);
+#pragma unroll
+            for (int p = 0; p < PB; ++p) vo[PA + p] = (use2 ? b_off2[p] : b_off[p]) + kg;
+            if (use2) kglob2 += BK;
+            else kglob += BK;
+            ++t_load;
+        };
+        auto issue_piece = [&](auto qc, int bufd) {      // piece q of the prepared tile -> LDS buffer bufd
+            constexpr int q = decltype(qc)::value;
+            const unsigned voff = vo[q];                 // (a by-value copy: with `vo[q]` as the builtin's operand hipcc's host
+                                                         //  pass silently drops the kernel's stub -- undefined symbol at load)
+            if constexpr (q < PA) {
+                float* dst = As + bufd * BM * LDSK + wave * PA * 16 * LDSK;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsTa, (lds_ptr_t)dst, 16, voff, 0, q * 1024, 0);
+            } else {
+                float* dst = Bs + bufd * BN * LDSK + wave * PB * 16 * LDSK;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsTb, (lds_ptr_t)dst, 16, voff, 0, (q - PA) * 1024, 0);
+            }
+        };
+        auto read_ops = [&](int bufr, int k8, f32x4 (&fa)[RT], f32x4 (&fb)[CT]) {
+            const int koff = ((2 * k8 + lh) ^ xr) * 4;
+            const float* a = As + bufr * BM * LDSK + (wr * RT * 32 + li) * LDSK + koff;
+            const float* b = Bs + bufr * BN * LDSK + (wc * CT * 32 + li) * LDSK + koff;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSK);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSK);
+        };
+        auto mfma_row = [&](const f32x4 (&fa)[RT], const f32x4 (&fb)[CT], int kk, int i) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+        };
+        // prologue: all three buffers requested, tile 0 landed, its first chunk in registers
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            prepare_next();
+            static_for<LT>([&](auto qc) { issue_piece(qc, b); });
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4 fa0[RT], fb0[CT], fa1[RT], fb1[CT];
+        read_ops(0, 0, fa0, fb0);
+        int buf = 0;
+        for (int t = 0; t < nAll; ++t) {
+            read_ops(buf, 1, fa1, fb1);
+            prepare_next();                              // tile t + 3 (address math only)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < RT; ++i) mfma_row(fa0, fb0, kk, i);
+            // every fragment of tile t is in registers; tile t + 1 has landed (tile t + 2 may stay in flight)
+            __builtin_amdgcn_sched_barrier(0);           // (keeps the MFMAs above: hipcc would sink them below the barrier)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int bufn1 = buf == 2 ? 0 : buf + 1;
+            read_ops(bufn1, 0, fa0, fb0);                // (past the last tile: stale bytes that nothing uses -- an unconditional
+                                                         // read keeps hipcc's own lgkmcnt bookkeeping off the MFMAs below)
+            __builtin_amdgcn_sched_barrier(0);           // tile t + 3 -> the buffer of tile t, one piece per MFMA row group
+            static_for<4 * RT>([&](auto gc) {
+                constexpr int grp = decltype(gc)::value;
+                mfma_row(fa1, fb1, grp / RT, grp % RT);
+                if constexpr (grp < LT) {
+                    if (TTS_ABL != 10) issue_piece(gc, buf);     // (ablation 10: the rotated loop without its DMA issue)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            static_assert(LT <= 4 * RT, "one DMA piece per MFMA row group");
+            buf = bufn1;
+        }
+        // the last three steps issued fetch-nothing pieces: they must have written their zeros before the epilogue reuses LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (DMA) {
         // NBUF (3 or 4) LDS buffers.  Step t: issue tile t+NBUF-1's DMA into the buffer read at step t-1 (every wave has
         // passed the barrier that ended that step), run tile t's MFMAs, then wait until all but the newest NBUF-2 tiles'
         // DMA have landed (counted vmcnt: tile t+1 is in LDS) and barrier.  No VGPR staging, no ds_write.
@@ -590,7 +758,11 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0, bufn = NBUF - 1;                // buffer of tile t, buffer for tile t + NBUF - 1
+#ifdef TTS_ABL_F32
+        constexpr int ABL = TTS_ABL;                 // measurement builds: the same ablations on the fp32 loop
+#else
         constexpr int ABL = HALF ? TTS_ABL : 0;      // timing ablations of the fp16 loop (results are garbage when != 0)
+#endif
         for (int t = 0; t < nAll; ++t) {
             if (ABL != 2 && loader) dma_tile(bufn);
             if (ABL != 3) {
