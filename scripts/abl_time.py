@@ -23,7 +23,8 @@ for prec in sys.argv[1:] or ('f16', 'f16x3'):
     e.kernel_timing(True)
     e.waveglow_infer(mel, z=z, precision=prec)
     us, n = e.kernel_time_us(0)
+    us1, n1 = e.kernel_time_us(1)        # residual GEMM
     us2, n2 = e.kernel_time_us(2)        # debug builds with TTS_TIME_SPLIT_DIL=1: the layers with dilation >= 32
     e.kernel_timing(False)
-    print(f"{os.environ.get('TTS_HIP_LIBRARY', 'default')} {prec}: {dt * 1e3:.1f} ms/step, in-layer {us:.0f} us x {n}"
+    print(f"{os.environ.get('TTS_HIP_LIBRARY', 'default')} {prec}: {dt * 1e3:.1f} ms/step, in-layer {us:.0f} us x {n}, residual {us1:.0f} us x {n1}"
           + (f", dilation >= 32: {us2:.0f} us x {n2}" if n2 else ''), flush=True)

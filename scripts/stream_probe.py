@@ -14,10 +14,12 @@ from text_to_speech_amd.waveglow import WaveGlow
 prec = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 n_sent = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 sampled = len(sys.argv) > 3 and sys.argv[3] == 'sampled'      # prenet dropout masks + WaveGlow noise sampled per call
+dec_mode = sys.argv[4] if len(sys.argv) > 4 else 'auto'       # decoder machine: auto (persistent at batch 1) | graph | ...
 e1, e2 = HipEngine(0), HipEngine(0)
 tw, ww = weights.synth_tacotron2(Tacotron2Config(), seed=1234), weights.synth_waveglow(WaveGlowConfig())
 for e in (e1, e2):
     e.load_state(tw); e.load_state(ww); e.finalize()
+e1.set_decoder_mode(dec_mode)
 model = Tacotron2(HipRuntime('t', model='tacotron2', engine=e1, seed=0, synthesizer_precision='f16' if prec == 'f16' else 'f32'))
 voc_same = WaveGlow(HipRuntime('w', model='waveglow', engine=e1, seed=0, vocoder_precision=prec))
 voc_own = WaveGlow(HipRuntime('w2', model='waveglow', engine=e2, seed=0, vocoder_precision=prec))
@@ -32,4 +34,4 @@ for name, v, ov in (('sequential', voc_same, False), ('overlapped', voc_own, Tru
     t0 = time.perf_counter()
     model.predict(texts, vocoder=v, overlap=ov, callbacks=[lambda time, **_: secs.append(time)], **kw)
     dt = time.perf_counter() - t0
-    print(f'{name} [{prec}{", sampled" if sampled else ""}]: {n_sent} sentences, {sum(secs):.1f} s of audio in {dt*1e3:.0f} ms = {sum(secs)/dt:.0f}x real time', flush=True)
+    print(f'{name} [{prec}{", sampled" if sampled else ""}, decoder {dec_mode} -> {e1.last_decoder_mode}]: {n_sent} sentences, {sum(secs):.1f} s of audio in {dt*1e3:.0f} ms = {sum(secs)/dt:.0f}x real time', flush=True)
