@@ -302,6 +302,7 @@ def secondary_metrics(eng, dev, rank):
 
 # ------------------------------------------------------------------------------------- BASELINE config 4 (sharded job)
 CONFIG4_UTTERANCES, CONFIG4_FRAMES, CONFIG4_TIN = 32, 400, 256
+CONFIG4_TIMEOUT_S = 240                     # watchdog of the config-4 job (a normal run takes a few seconds)
 
 
 def config4_job(eng, dev, rank, world, reps=2):
@@ -413,6 +414,47 @@ def launch_ranks(n: int, argv) -> int:
     return worst
 
 
+def headline_result(args, world, B, T, dt, avg_us, launches, distributed):
+    """The JSON line without its secondary parts (CPU baseline, config-4 job, extras), from the timed region's numbers."""
+    samples = world * B * T * 256 * args.steps
+    M = B * T * 32
+    roofline = None
+    if launches and args.precision != 'f32':
+        # fp16 matrix pipe (2.5 PFLOP/s dense): the split mode issues three MFMAs per product
+        mfma_flops = wn_in_layer_flops(M) * (3 if args.precision == 'f16x3' else 1)
+        achieved = mfma_flops / (avg_us * 1e-6) / 1e12
+        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': achieved / FP16_MFMA_PEAK_TFLOPS,
+                    'flops_per_launch': mfma_flops, 'traffic': None, 'launches_timed': launches,
+                    'avg_launch_us': avg_us,
+                    'kernel': 'WN in-layer implicit GEMM, fp16 MFMA (' + args.precision + ')'}
+    elif launches:
+        achieved = wn_in_layer_flops(M) / (avg_us * 1e-6) / 1e12
+        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+                    'flops_per_launch': wn_in_layer_flops(M),
+                    'reference_formulation_tflops': wn_in_layer_flops(M, K_REFERENCE) / (avg_us * 1e-6) / 1e12,
+                    'traffic': pmc_traffic_bytes(B, T),
+                    'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
+                    'algorithmic_bytes': (M * (512 + 512) + B * T * 80 + 1024 * (1536 + 32 * 320)) * 4.0,
+                    'kernel': 'gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; K = 1536 taps + 320 folded conditioning)', 'launches_timed': launches,
+                    'avg_launch_us': avg_us}
+    return {
+        'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)' if args.precision == 'f32' else
+                  f'audio samples/sec (22.05 kHz WaveGlow vocoding, {args.precision})',
+        'value': samples / dt, 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': f'WaveGlow-only vocoding of precomputed 80x{T} mel, batch {B} per GPU, fp32 '
+                               f'(BASELINE.json configs[1])', 'batch_per_gpu': B, 'mel_frames': T,
+                   'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
+                   'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
+                   'weights': 'seeded synthetic (rng 1234)'},
+        'x_realtime': samples / dt / SAMPLE_RATE,
+        'roofline': roofline, 'cpu_baseline': None, 'config4_sharded_job': None, 'extra': None,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -510,60 +552,49 @@ def main():
 
     avg_us, launches = (0.0, 0) if args.no_kernel_timing else eng.kernel_time_us(KERNEL_WN_IN)
     eng.kernel_timing(False)
-    # BASELINE config 4: the scatter / synthesize / gather job, on every rank, at every N
+    # BASELINE config 4: the scatter / synthesize / gather job, on every rank, at every N.  It must never cost the headline
+    # line: an exception is reported inside the line, and a job that does not come back (a rank lost inside a collective
+    # leaves the others waiting) is cut off by a watchdog thread that lets rank 0 print the line without it.
     config4 = None
+    watchdog = None
+    headline = {'ready': False}
+
+    def give_up():
+        if rank == 0 and headline['ready']:
+            headline['result']['config4_sharded_job'] = {'error': f'no result after {CONFIG4_TIMEOUT_S} s (cut off by the watchdog)'}
+            print(json.dumps(headline['result']), flush=True)
+        os._exit(0 if headline['ready'] or rank != 0 else 1)
     if not args.no_config4:
+        import threading
+        if rank == 0:
+            headline['result'] = headline_result(args, world, B, T, dt, avg_us, launches, distributed)
+            headline['ready'] = True
+        watchdog = threading.Timer(CONFIG4_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             config4 = config4_job(eng, dev, rank, world)
         except Exception as exc:                                 # never lose the headline line to the secondary job
             config4 = {'error': f'{type(exc).__name__}: {exc}'} if rank == 0 else None
+        watchdog.cancel()
     # secondary metrics and the CPU leg only at N = 1 (the other ranks would idle at the final barrier)
     extra = secondary_metrics(eng, dev, rank) if (rank == 0 and world == 1 and not args.no_extra) else None
-    samples = world * B * T * 256 * args.steps
     if rank == 0:
-        M = B * T * 32
-        roofline = None
-        if launches and args.precision != 'f32':
-            # fp16 matrix pipe (2.5 PFLOP/s dense): the split mode issues three MFMAs per product
-            mfma_flops = wn_in_layer_flops(M) * (3 if args.precision == 'f16x3' else 1)
-            achieved = mfma_flops / (avg_us * 1e-6) / 1e12
-            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / FP16_MFMA_PEAK_TFLOPS,
-                        'flops_per_launch': mfma_flops, 'traffic': None, 'launches_timed': launches,
-                        'avg_launch_us': avg_us,
-                        'kernel': 'WN in-layer implicit GEMM, fp16 MFMA (' + args.precision + ')'}
-        elif launches:
-            achieved = wn_in_layer_flops(M) / (avg_us * 1e-6) / 1e12
-            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                        'flops_per_launch': wn_in_layer_flops(M),
-                        'reference_formulation_tflops': wn_in_layer_flops(M, K_REFERENCE) / (avg_us * 1e-6) / 1e12,
-                        'traffic': pmc_traffic_bytes(B, T),
-                        'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
-                        'algorithmic_bytes': (M * (512 + 512) + B * T * 80 + 1024 * (1536 + 32 * 320)) * 4.0,
-                        'kernel': 'gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; K = 1536 taps + 320 folded conditioning)', 'launches_timed': launches,
-                        'avg_launch_us': avg_us}
-        cpu = None
+        result = headline_result(args, world, B, T, dt, avg_us, launches, distributed)
         if args.cpu_frames > 0 and world == 1:
-            cpu = cpu_baseline(w, cfg, args.cpu_frames)
-        result = {
-            'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)' if args.precision == 'f32' else
-                      f'audio samples/sec (22.05 kHz WaveGlow vocoding, {args.precision})',
-            'value': samples / dt, 'unit': 'audio samples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': f'WaveGlow-only vocoding of precomputed 80x{T} mel, batch {B} per GPU, fp32 '
-                                   f'(BASELINE.json configs[1])', 'batch_per_gpu': B, 'mel_frames': T,
-                       'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
-                       'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
-                       'weights': 'seeded synthetic (rng 1234)'},
-            'x_realtime': samples / dt / SAMPLE_RATE,
-            'roofline': roofline, 'cpu_baseline': cpu, 'config4_sharded_job': config4, 'extra': extra,
-        }
+            result['cpu_baseline'] = cpu_baseline(w, cfg, args.cpu_frames)
+        result['config4_sharded_job'] = config4
+        result['extra'] = extra
         print(json.dumps(result), flush=True)
     if distributed:
+        # the line is out: a rank that is gone must not keep the others (and the driver) at this barrier
+        import threading
+        bye = threading.Timer(60, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
     eng.close()
 
 
