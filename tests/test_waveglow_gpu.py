@@ -151,6 +151,37 @@ def test_waveglow_256_row_tiles_match_oracle(gpu_engine, wg_weights, wg_cfg):
     assert err <= RMS_TOL and err16 <= F16_RMS_TOL
 
 
+def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_weights, wg_cfg):
+    """The exact-fp32 path evaluates WN layers 1 - 7 in their Winograd F(2,3) form when the call takes the 256-row tiles and
+    the utterance length is a multiple of 8 frames (csrc/wn_wino.hip): both forms against the oracle on the same inputs, the
+    switch, the report of which one ran, and the fall-back for a length that is not a multiple of 8."""
+    from oracle import waveglow_ref
+    mel, z = _inputs(2, 128, seed=33)
+    ref = waveglow_ref.infer(mel, wg_weights, wg_cfg, z=z, sigma=1.0)
+    try:
+        wino = gpu_engine.waveglow_infer(mel, z=z, sigma=1.0)
+        assert gpu_engine.last_waveglow_form == 'winograd'
+        gpu_engine.set_waveglow_form('direct')
+        direct = gpu_engine.waveglow_infer(mel, z=z, sigma=1.0)
+        assert gpu_engine.last_waveglow_form == 'direct'
+    finally:
+        gpu_engine.set_waveglow_form('winograd')
+    e_w, e_d, diff = rms(wino - ref), rms(direct - ref), rms(wino - direct)
+    print(f'winograd rms_err={e_w:.3e}  direct rms_err={e_d:.3e}  winograd vs direct {diff:.3e}')
+    assert e_w <= RMS_TOL and e_d <= RMS_TOL and diff <= 5e-6
+    # 2 x 126 frames: the same 256-row tiles, but pairs of frames would straddle the utterances -> direct form
+    mel2, z2 = _inputs(2, 126, seed=34)
+    out2 = gpu_engine.waveglow_infer(mel2, z=z2, sigma=1.0)
+    assert gpu_engine.last_waveglow_form == 'direct'
+    assert rms(out2 - waveglow_ref.infer(mel2, wg_weights, wg_cfg, z=z2, sigma=1.0)) <= RMS_TOL
+    # small calls (64- / 128-row tiles) always take the direct form; the fp16 modes have no Winograd form
+    m3, z3 = _inputs(1, 16, seed=35)
+    gpu_engine.waveglow_infer(m3, z=z3)
+    assert gpu_engine.last_waveglow_form == 'direct'
+    with pytest.raises(ValueError):
+        gpu_engine.set_waveglow_form('fft')
+
+
 def test_waveglow_config2_rows_equal_batch1_runs(gpu_engine):
     """Full BASELINE.json config 2 (8 x 800 frames, 256-row tiles) against batch-1 runs of single rows (128-row tiles):
     a size-independent property (utterances are independent) that also cross-checks the two tile configurations."""

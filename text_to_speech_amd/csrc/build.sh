@@ -12,7 +12,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 mkdir -p "$bdir"
 objs=()
 pids=()
-for src in engine waveglow tacotron2 taco_persist taco_fused mel_stft; do
+for src in engine waveglow wn_wino tacotron2 taco_persist taco_fused mel_stft; do
   obj="$bdir/$src.o"
   objs+=("$obj")
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/gemm_f32.h" -nt "$obj" || "$here/engine.h" -nt "$obj" \

@@ -53,6 +53,9 @@ struct WgLayerDev {
     _Float16* in_Bt_x3 = nullptr;   // split-fp16 mode: the same three matrices as [2 planes][...] (hi, lo), built on first use
     _Float16* cond_Bt_x3 = nullptr;
     _Float16* rs_Bt_x3 = nullptr;
+    float* wino_G = nullptr;    // Winograd form (wn_wino.hip; built on first use): [4][1024][512] tap combinations,
+    float* wino_V = nullptr;    //   [16 or 32][4][1024][160] conditioning halves, [4][1024] bias planes
+    float* wino_bias = nullptr;
     float* rs_Bt = nullptr;     // [512][512] residual half of res_skip (layers 0..6)
     float* rs_bias = nullptr;   // [512]
     int rs_n = 0;
@@ -73,6 +76,9 @@ struct WaveGlowDev {
     DevBuf x, acts, audio, a0p, io_mel, io_z, io_out, io_zgen;
     bool f16_ready = false, x3_ready = false;
     DevBuf x16, acts16, a0p16, mel16;        // fp16 path: shadow of x, activations, first-layer operand, mel
+    int form_mode = 1, last_form = -1;       // tts_hip_set_waveglow_form / tts_hip_last_waveglow_form
+    bool wino_ready = false;                 // Winograd form of the fp32 in-layer GEMM (wn_wino.hip)
+    DevBuf wino_U, wino_P, wino_mel;         // transformed inputs [4][M/2][512], products [4][M/2][1024], mel planes
 };
 
 // ---------------------------------------------------------------- Tacotron2
@@ -199,6 +205,10 @@ void tacotron2_graphs_clear(tts_hip_engine* e);
             return set_err((e), TTS_HIP_EHIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_err)); \
     } while (0)
 
+// Winograd form of the WN in-layer GEMM (wn_wino.hip)
+int waveglow_build_wino(tts_hip_engine* e);
+int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T);
+int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const float* x, float* acts_i, int PR, int BT, int T);
 // timing helpers (engine.hip)
 void timing_begin(tts_hip_engine* e, int kind);
 void timing_end(tts_hip_engine* e);

@@ -134,7 +134,7 @@ int philox_fill(tts_hip_engine* e, float* out, long long n, uint64_t seed, uint6
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 8; }
+int tts_hip_abi_version(void) { return 9; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -496,6 +496,14 @@ int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode) {
 }
 
 int tts_hip_last_decoder_mode(const tts_hip_engine* e) { return e ? e->taco.last_path : -1; }
+
+int tts_hip_set_waveglow_form(tts_hip_engine* e, int form) {
+    if (!e || form < 0 || form > 1) return set_err(e, TTS_HIP_EINVAL, "set_waveglow_form: form must be 0 (direct) or 1 (Winograd when the call shape allows it)");
+    e->wg.form_mode = form;
+    return TTS_HIP_OK;
+}
+
+int tts_hip_last_waveglow_form(const tts_hip_engine* e) { return e ? e->wg.last_form : -1; }
 
 int tts_hip_synchronize(tts_hip_engine* e) {
     if (!e) return TTS_HIP_EINVAL;

@@ -71,7 +71,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // shift per block while making the phase block-uniform (needed for the per-phase conditioning weights).
 enum { SEG_ROWS = 0,        // operand row = m + shift
        SEG_PHASE_TAP = 1,   // shift counts sample groups: phase' = (p + shift) mod 32, frame carry = floor((p + shift) / 32)
-       SEG_FRAME = 2 };     // operand row = f + shift (same operand for every phase, e.g. the mel frames)
+       SEG_FRAME = 2,       // operand row = f + shift (same operand for every phase, e.g. the mel frames)
+       SEG_ROWS_Z = 3,      // operand row = m + blockIdx.z * zrows (one operand plane per z slice; no sequence bounds)
+       SEG_FRAME_Z = 4 };   // operand row = f + blockIdx.z * zrows
 struct ASeg {
     const float* ptr;   // row m of the operand lives at ptr + (m + shift) * ld
     long long ld;       // row stride in floats
@@ -80,6 +82,8 @@ struct ASeg {
     int kpad;           // K extent in Bt (multiple of BK, zero padded)
     int kind;           // SEG_ROWS / SEG_PHASE_TAP / SEG_FRAME
     long long plane;    // PL == 2 kernels: offset (in floats) of the operand's second fp16 plane (the "lo" halves)
+    long long zrows;    // SEG_ROWS_Z / SEG_FRAME_Z: rows between the operand planes of consecutive z slices
+    int b1;             // a sequential segment that multiplies the FIRST weight matrix (Bt) although Bt2 is set
 };
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
@@ -105,6 +109,8 @@ struct GemmArgs {
     const float* Bt2;               // optional second weight matrix for the sequential segments [phase][N][ldb2]
     long long ldb2;
     long long strideB2p;            // per-phase stride of Bt2 (0: shared)
+    long long strideB2z;            // per-blockIdx.z stride of Bt2
+    int nphase;                     // phase blocks in M (0 = 32)
     // ---- epilogue
     int mode;                       // EPI_LINEAR / EPI_GATE
     int act;
@@ -333,6 +339,12 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         } else if (sg.kind == SEG_FRAME) {
             vshift = sg.shift;
             abs_row = (long long)f0 + sg.shift;
+        } else if (sg.kind == SEG_ROWS_Z) {
+            vshift = 0;
+            abs_row = (long long)m0 + z * sg.zrows;
+        } else if (sg.kind == SEG_FRAME_Z) {
+            vshift = 0;
+            abs_row = (long long)f0 + z * sg.zrows;
         } else {
             vshift = sg.shift + (int)z * g.shift_z;
             abs_row = (long long)m0 + vshift;
@@ -349,6 +361,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     int s_cur = NI, kc_cur = 0, kglob = 0, kglob2 = 0;
     int seg_k = 0, seg_kpad = 0;
     unsigned seg_plane = 0;                          // byte offset of the current sequential segment's second plane
+    bool seg_b1 = false;                             // the current sequential segment multiplies Bt (not Bt2)
     __amdgpu_buffer_rsrc_t rsA;
     const float* ptrSeqA = nullptr;                  // base of rsA (the rotated loop rebuilds descriptors from pointers)
     unsigned a_off[PA];
@@ -357,6 +370,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
         seg_k = sg.k;
         seg_kpad = sg.kpad;
         seg_plane = (unsigned)(sg.plane * 4);
+        seg_b1 = sg.b1 != 0;
         long long abs_row;
         int vshift;
         seg_row(sg, abs_row, vshift);
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
     // second weight matrix (per-phase) for the sequential segments
     const bool B2 = g.Bt2 != nullptr;
     const float* const bbase1 = g.Bt + z * g.strideBz + (long long)n0 * g.ldb;
-    const float* const bbase2 = (B2 ? g.Bt2 : g.Bt) + (long long)ph * g.strideB2p + (long long)n0 * g.ldb2;
+    const float* const bbase2 = (B2 ? g.Bt2 + z * g.strideB2z : g.Bt) + (long long)ph * g.strideB2p + (long long)n0 * g.ldb2;
     unsigned b_off2[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p)
@@ -435,6 +449,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 
     auto fetch_next = [&](auto&& emit) {             // issues the loads of tile `t_load` (if any) and advances
         if (t_load < nAll) {
+            bool cur_b1 = false;
             if (NI > 0 && t_load < nI) {
                 const unsigned delta = delta_of(si) + (unsigned)(kci * BK * 4);
                 const bool kok = kci * BK + c4 < kI;
@@ -456,6 +471,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                 const unsigned kb = (unsigned)(kc_cur * BK * 4);
                 const bool kok = kc_cur * BK + c4 < seg_k;
                 const unsigned pl_a = seg_plane;     // (read before a segment crossing below may change it)
+                cur_b1 = seg_b1;
 #pragma unroll
                 for (int p = 0; p < PA; ++p) emit(true, p, rsA, kok ? a_off[p] + kb : OOB, pl_a);
                 if (++kc_cur * BK >= seg_kpad) {
@@ -464,7 +480,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                 }
             }
             // weight tile: the sequential segments may use their own (per-phase) matrix Bt2
-            const bool use2 = B2 && !(NI > 0 && t_load < nI);
+            const bool use2 = B2 && !(NI > 0 && t_load < nI) && !cur_b1;
             const __amdgpu_buffer_rsrc_t rsW = make_rsrc_uniform(use2 ? bbase2 : bbase1);
             const unsigned kg = (unsigned)((use2 ? kglob2 : kglob) * 4);
             const unsigned pl_b = (unsigned)((use2 ? g.planeB2 : g.planeB) * 4);
@@ -625,6 +641,7 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                 return;
             }
             const bool inter = NI > 0 && t_load < nI;
+            bool cur_b1 = false;
             if (inter) {
                 const unsigned delta = delta_of(si) + (unsigned)(kci * BK * 4);
                 const bool kok = kci * BK + c4 < kI;
@@ -644,12 +661,13 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 #pragma unroll
                 for (int p = 0; p < PA; ++p) vo[p] = kok ? a_off[p] + kb : OOB;
                 rsTa = make_rsrc_uniform(ptrSeqA - ROT_SH / 4);
+                cur_b1 = seg_b1;
                 if (++kc_cur * BK >= seg_kpad) {
                     kc_cur = 0;
                     if (++s_cur < g.nseg) enter_segment();      // (rsA changes for the NEXT tile; rsTa keeps this tile's copy)
                 }
             }
-            const bool use2 = B2 && !inter;
+            const bool use2 = B2 && !inter && !cur_b1;
             rsTb = make_rsrc_uniform((use2 ? bbase2 : bbase1) - ROT_SH / 4);
             const unsigned kg = (unsigned)((use2 ? kglob2 : kglob) * 4);
 #pragma unroll
@@ -983,8 +1001,9 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
     if (g.split < g.N && g.split % BN != 0) return hipErrorInvalidValue;     // output side must be uniform per block
     if (g.phase_rows > 0) {
         // tiles must not straddle phases; the interleaved-tap descriptor spans at most the whole operand (31-bit offsets)
-        if (g.phase_rows % BM != 0 || g.M != 32 * g.phase_rows) return hipErrorInvalidValue;
-        if (32.0 * g.phase_rows * (double)g.seg[0].ld * 4.0 >= 2147483648.0 - 65536.0) return hipErrorInvalidValue;
+        const int nph = g.nphase > 0 ? g.nphase : 32;
+        if (g.phase_rows % BM != 0 || g.M != nph * g.phase_rows) return hipErrorInvalidValue;
+        if ((double)nph * g.phase_rows * (double)g.seg[0].ld * 4.0 >= 2147483648.0 - 65536.0) return hipErrorInvalidValue;
     }
     if (g.wide_epi) {
         if (PIPE != PIPE_DMA || g.rowmask || g.M % BM != 0 || g.N % BN != 0 || g.ld0 % 4 != 0 ||
@@ -1009,7 +1028,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int batch_z, hipStream_t stream
 }
 
 // Tile configurations: BIG = 256x128 (WN layers, upsampling); SMALL = 64x64 (Tacotron2-sized problems).
-enum { TAG_GENERIC = 0, TAG_WN_IN = 1, TAG_WN_RES_SKIP = 2, TAG_WN_IN0 = 3 };
+enum { TAG_GENERIC = 0, TAG_WN_IN = 1, TAG_WN_RES_SKIP = 2, TAG_WN_IN0 = 3, TAG_WN_WINO = 4 };
 #ifndef TTS_WN_BK
 #define TTS_WN_BK 16
 #define TTS_WN_OCC 2
@@ -1097,6 +1116,9 @@ inline hipError_t gemm_wn_in0(const GemmArgs& g, hipStream_t s) { return launch_
 #define TTS_WN_RES_OCC 3
 #endif
 inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RES_RT, 4, TTS_WN_BK, TTS_WN_RES_OCC, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
+// Winograd form of the in-layer GEMM (wn_wino.hip): four z slices (one per product) on pair rows, K = 512 + 160 each
+inline hipError_t gemm_wn_wino(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_WINO, 0, TTS_WN_PIPE>(g, 4, s); }
+inline hipError_t gemm_wn_wino_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_WINO, 0, TTS_WN_PIPE>(g, 4, s); }
 inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1, 32, 1, TAG_GENERIC>(g, bz, s); }
 
 }  // namespace ttsgemm

@@ -389,6 +389,10 @@ void waveglow_free(tts_hip_engine* e) {
     e->wg.acts16.release();
     e->wg.a0p16.release();
     e->wg.mel16.release();
+    e->wg.wino_U.release();
+    e->wg.wino_P.release();
+    e->wg.wino_mel.release();
+    e->wg.wino_ready = false;
     e->wg.f16_ready = false;
     e->wg.x3_ready = false;
     e->wg.io_mel.release();
@@ -752,6 +756,14 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
     }
     hipStream_t st = e->stream;
+    // exact-fp32 path, 256-row tiles: layers 1 .. 7 of a flow run in their Winograd form (wn_wino.hip)
+    const bool wino = precision == 0 && !row64 && !tile128 && !tile64 && T % 8 == 0 && wg.form_mode == 1;
+    wg.last_form = wino ? 1 : 0;
+    if (wino) {
+        int rc = waveglow_build_wino(e);
+        if (!rc) rc = waveglow_wino_begin(e, d_mel, PR, BT, T);
+        if (rc) return rc;
+    }
     _Float16* x16 = (_Float16*)wg.x16.p;
     _Float16* acts16 = (_Float16*)wg.acts16.p;
     _Float16* mel16 = (_Float16*)wg.mel16.p;
@@ -813,10 +825,15 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                 float* acts_i = wg.acts.f() + (size_t)i * M * C;
                 g.out0 = acts_i;
                 g.ld0 = C;
-                timing_begin(e, i == 0 ? 3 : 0);
-                if (i == 0) HIPCHK(e, row64 ? gemm_wn_in0_r64(g, st) : tile64 ? gemm_wn_in0_64(g, st) : tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
-                else HIPCHK(e, row64 ? gemm_wn_in_r64(g, st) : tile64 ? gemm_wn_in_64(g, st) : tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
-                timing_end(e);
+                if (wino && i > 0) {
+                    const int rc = waveglow_wino_layer(e, ly, i, wg.x.f(), acts_i, PR, BT, T);
+                    if (rc) return rc;
+                } else {
+                    timing_begin(e, i == 0 ? 3 : 0);
+                    if (i == 0) HIPCHK(e, row64 ? gemm_wn_in0_r64(g, st) : tile64 ? gemm_wn_in0_64(g, st) : tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
+                    else HIPCHK(e, row64 ? gemm_wn_in_r64(g, st) : tile64 ? gemm_wn_in_64(g, st) : tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
+                    timing_end(e);
+                }
                 if (i < 7) {             // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
                     GemmArgs r{};
                     r.M = (int)M;

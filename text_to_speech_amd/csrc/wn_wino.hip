@@ -1,0 +1,302 @@
+// wn_wino.hip -- Winograd F(2,3) along the tap axis of the WN dilated convolution (exact-fp32 path, large batches).
+//
+// The in-layer pre-activation of WaveGlow's WN (/root/reference/architectures/waveglow_arch.py:117-127) is a k = 3 dilated
+// convolution plus the conditioning term,  y[l] = W- x[l - d] + W0 x[l] + W+ x[l + d] + c[l] + b.  Two outputs one dilation
+// apart, y0 = y[l] and y1 = y[l + d], share the inputs x[l - d], x[l], x[l + d], x[l + 2d]; the minimal-filtering form
+//     m0 = (x[l-d] - x[l+d]) W-            m1 = (x[l] + x[l+d]) (W- + W0 + W+) / 2
+//     m2 = (x[l+d] - x[l]) (W- - W0 + W+) / 2        m3 = (x[l] - x[l+2d]) W+
+//     y0 = m0 + m1 + m2 + c0 + b           y1 = m1 - m2 - m3 + c1 + b
+// needs four K = 512 products per output PAIR instead of six: K per output 1024 instead of 1536.  The conditioning term
+// (K = 320 per output) rides along without leaving any of the four products idle: its first half (K = 160) goes into the
+// products that feed one output only (m0 for y0, -m3 for y1) and, writing c0 = s + e, c1 = s - e, the second half as s into
+// m1 and as e into m2.  So a layer is ONE launch of the GEMM kernel of gemm_f32.h with four z slices (one per product) of
+// K = 512 + 160 each, on "pair rows", followed by a combine + gate pass:
+//
+//   pre-pass   x -> U[4][M/2][512]            (the four transformed inputs, one plane per product; HBM-bound)
+//   GEMM       P[z] = U[z] G[z]^T + melP[z] V[z]^T (+ b for z = 0, 3)        z = (m0, m1, m2, -m3)
+//   combine    y0 = P0 + P1 + P2,  y1 = P3 + P1 - P2,  acts = tanh(.) * sigmoid(.) written to both output rows
+//
+// Pairs: dilation d < 32 (sample groups): phases (p0, p0 + d) of the same frame, p0 = (pp / d) 2d + pp % d for the 16
+// "pair phases" pp -- the two outputs share their mel rows and differ in the per-phase conditioning weights, so s / e are
+// weight combinations (V_p0 +- V_p1) / 2.  Dilation >= 32 (s = d / 32 frames): frames (f0, f0 + s) of the same phase, f0 =
+// (fp / s) 2s + fp % s -- the outputs share the weights and s / e are combinations of mel rows.  Utterance lengths must be a
+// multiple of 8 frames (pairs never straddle an utterance), else the direct kernel runs.
+//
+// Numerics: every operand stays fp32 and all weight combinations are formed in fp64 and rounded once; the result differs
+// from the direct form by fp32 rounding only (it is not bit-identical to it).
+#include "engine.h"
+#include "gemm_f32.h"
+
+using namespace ttsgemm;
+
+namespace {
+constexpr int C = 512;
+constexpr int NPH = 32;
+constexpr int KMEL = 320, KH = 160;
+constexpr int KCONV = 3 * C;
+
+// (p0, p1) of pair phase pp for dilation d < 32
+__device__ __forceinline__ void pair_phases(int pp, int d, int& p0, int& p1) {
+    p0 = (pp / d) * 2 * d + pp % d;
+    p1 = p0 + d;
+}
+
+// x row of (phase ps -- may leave [0, 32): carried into the neighbouring frame -- , frame row f + df), zero outside the utterance
+__device__ __forceinline__ f32x4 x_at(const float* __restrict__ x, int ps, long long f, int df, int c, int PR, int BT, int T) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (f >= BT) return zero;
+    const int carry = (ps >> 5) + df;                  // arithmetic shift: floor
+    const int t = (int)(f % T) + carry;
+    if (t < 0 || t >= T) return zero;
+    return *reinterpret_cast<const f32x4*>(x + ((long long)(ps & 31) * PR + f + carry) * C + c);
+}
+
+// U planes (see the header).  One thread per (pair row, 4 channels).
+__global__ void wino_prepass_kernel(const float* __restrict__ x, float* __restrict__ U, int d, int PR, int BT, int T, long long Mh) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mh * (C / 4)) return;
+    const long long mp = idx / (C / 4);
+    const int c = (int)(idx % (C / 4)) * 4;
+    f32x4 xm, x0, x1, x2;
+    if (d < NPH) {
+        const int pp = (int)(mp / PR);
+        const long long f = mp % PR;
+        int p0, p1;
+        pair_phases(pp, d, p0, p1);
+        xm = x_at(x, p0 - d, f, 0, c, PR, BT, T);
+        x0 = x_at(x, p0, f, 0, c, PR, BT, T);
+        x1 = x_at(x, p1, f, 0, c, PR, BT, T);
+        x2 = x_at(x, p1 + d, f, 0, c, PR, BT, T);
+    } else {
+        const int s = d / NPH, half = PR / 2;
+        const int p = (int)(mp / half);
+        const long long fp = mp % half;
+        const long long f0 = (fp / s) * 2 * s + fp % s;
+        xm = x_at(x, p, f0, -s, c, PR, BT, T);
+        x0 = x_at(x, p, f0, 0, c, PR, BT, T);
+        x1 = x_at(x, p, f0, s, c, PR, BT, T);
+        x2 = x_at(x, p, f0, 2 * s, c, PR, BT, T);
+    }
+    const long long o = mp * C + c, plane = Mh * C;
+    *reinterpret_cast<f32x4*>(U + o) = xm - x1;
+    *reinterpret_cast<f32x4*>(U + plane + o) = x0 + x1;
+    *reinterpret_cast<f32x4*>(U + 2 * plane + o) = x1 - x0;
+    *reinterpret_cast<f32x4*>(U + 3 * plane + o) = x0 - x2;
+}
+
+// G[4][1024][512] from in_Bt [1024][1536] (K tap-interleaved in chunks of 16): (W-, (W- + W0 + W+) / 2, (W- - W0 + W+) / 2, -W+)
+__global__ void wino_weights_kernel(const float* __restrict__ in_Bt, float* __restrict__ G) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * C * C) return;
+    const int n = idx / C, c = idx % C;
+    const float* row = in_Bt + (long long)n * KCONV + (c / 16) * 48 + c % 16;
+    const double wm = row[0], w0 = row[16], wp = row[32];
+    const long long plane = (long long)2 * C * C;
+    G[idx] = (float)wm;
+    G[plane + idx] = (float)((wm + w0 + wp) * 0.5);
+    G[2 * plane + idx] = (float)((wm - w0 + wp) * 0.5);
+    G[3 * plane + idx] = (float)(-wp);
+}
+
+// V[npp][4][1024][160] from cond_Bt [32][1024][320]
+__global__ void wino_cond_weights_kernel(const float* __restrict__ cond_Bt, float* __restrict__ V, int d) {
+    const int npp = d < NPH ? NPH / 2 : NPH;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)npp * 2 * C * KH) return;
+    const int k = (int)(idx % KH), n = (int)((idx / KH) % (2 * C)), pp = (int)(idx / ((long long)KH * 2 * C));
+    int p0 = pp, p1 = pp;
+    if (d < NPH) pair_phases(pp, d, p0, p1);
+    const float* r0 = cond_Bt + ((long long)p0 * 2 * C + n) * KMEL;
+    const float* r1 = cond_Bt + ((long long)p1 * 2 * C + n) * KMEL;
+    const long long zs = (long long)2 * C * KH, o = (long long)pp * 4 * zs + (long long)n * KH + k;
+    V[o] = r0[k];                                                              // first half of c0 -> m0
+    V[o + 3 * zs] = r1[k];                                                     // first half of c1 -> -m3
+    if (d < NPH) {
+        V[o + zs] = (float)(((double)r0[KH + k] + (double)r1[KH + k]) * 0.5);  // s: weights averaged
+        V[o + 2 * zs] = (float)(((double)r0[KH + k] - (double)r1[KH + k]) * 0.5);
+    } else {
+        V[o + zs] = r0[KH + k];                                                // s / e are formed on the mel side
+        V[o + 2 * zs] = r0[KH + k];
+    }
+}
+
+// bias planes [4][1024] = (b, 0, 0, b)
+__global__ void wino_bias_kernel(const float* __restrict__ b, float* __restrict__ b4) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= 2 * C) return;
+    b4[n] = b[n];
+    b4[2 * C + n] = 0.f;
+    b4[4 * C + n] = 0.f;
+    b4[6 * C + n] = b[n];
+}
+
+// mel window of frame f: [mel_t | mel_{t-1} | mel_{t-2} | mel_{t-3}][80], zeros before the start of the utterance; column k
+__device__ __forceinline__ float melwin(const float* __restrict__ mel, long long f, int k, int BT, int T) {
+    if (f >= BT) return 0.f;
+    const int q = k / 80, j = k % 80;
+    return (int)(f % T) - q >= 0 ? mel[(f - q) * 80 + j] : 0.f;
+}
+
+// melP[4][rows][160]: the conditioning operands of the four products.  s = 0: dilations < 32 (rows = frames, planes
+// (lo, hi, hi, lo) halves of the window); s > 0: frame pairs (f0, f0 + s): (lo(f0), (hi(f0) + hi(f1)) / 2, (hi(f0) - hi(f1)) / 2, lo(f1))
+__global__ void wino_mel_planes_kernel(const float* __restrict__ mel, float* __restrict__ P, int s, int rows, int BT, int T) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * KH) return;
+    const long long r = idx / KH;
+    const int k = (int)(idx % KH);
+    const long long plane = (long long)rows * KH;
+    if (s == 0) {
+        const float lo = melwin(mel, r, k, BT, T), hi = melwin(mel, r, KH + k, BT, T);
+        P[idx] = lo;
+        P[plane + idx] = hi;
+        P[2 * plane + idx] = hi;
+        P[3 * plane + idx] = lo;
+    } else {
+        const long long f0 = (r / s) * 2 * s + r % s, f1 = f0 + s;
+        const float h0 = melwin(mel, f0, KH + k, BT, T), h1 = melwin(mel, f1, KH + k, BT, T);
+        P[idx] = melwin(mel, f0, k, BT, T);
+        P[plane + idx] = 0.5f * (h0 + h1);
+        P[2 * plane + idx] = 0.5f * (h0 - h1);
+        P[3 * plane + idx] = melwin(mel, f1, k, BT, T);
+    }
+}
+
+// y0 = P0 + P1 + P2, y1 = P3 + P1 - P2; acts = tanh * sigmoid (column groups of 64: 32 tanh, then their 32 sigmoid partners)
+__global__ void wino_combine_kernel(const float* __restrict__ P, float* __restrict__ acts, int d, int PR, long long Mh) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mh * (C / 4)) return;
+    const long long mp = idx / (C / 4);
+    const int ch = (int)(idx % (C / 4)) * 4;
+    const int col = (ch >> 5) * 64 + (ch & 31);
+    const long long plane = Mh * 2 * C, o = mp * 2 * C + col;
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+        a[z] = *reinterpret_cast<const f32x4*>(P + z * plane + o);
+        b[z] = *reinterpret_cast<const f32x4*>(P + z * plane + o + 32);
+    }
+    const f32x4 t0 = a[0] + a[1] + a[2], s0 = b[0] + b[1] + b[2];
+    const f32x4 t1 = a[3] + a[1] - a[2], s1 = b[3] + b[1] - b[2];
+    f32x4 g0, g1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        g0[k] = gate_tanh_sigmoid(t0[k], s0[k]);
+        g1[k] = gate_tanh_sigmoid(t1[k], s1[k]);
+    }
+    long long r0, r1;
+    if (d < NPH) {
+        const int pp = (int)(mp / PR);
+        const long long f = mp % PR;
+        int p0, p1;
+        pair_phases(pp, d, p0, p1);
+        r0 = (long long)p0 * PR + f;
+        r1 = (long long)p1 * PR + f;
+    } else {
+        const int s = d / NPH, half = PR / 2;
+        const int p = (int)(mp / half);
+        const long long fp = mp % half;
+        const long long f0 = (fp / s) * 2 * s + fp % s;
+        r0 = (long long)p * PR + f0;
+        r1 = r0 + s;
+    }
+    *reinterpret_cast<f32x4*>(acts + r0 * C + ch) = g0;
+    *reinterpret_cast<f32x4*>(acts + r1 * C + ch) = g1;
+}
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+}  // namespace
+
+// Per-layer operands (once, on the first call that takes this path): G, V and the bias planes of layers 1 .. 7 of every flow
+int waveglow_build_wino(tts_hip_engine* e) {
+    WaveGlowDev& wg = e->wg;
+    if (wg.wino_ready) return TTS_HIP_OK;
+    hipStream_t st = e->stream;
+    for (int k = 0; k < 12; ++k)
+        for (int i = 1; i < 8; ++i) {
+            WgLayerDev& ly = wg.flow[k].layer[i];
+            const int d = 1 << i, npp = d < NPH ? NPH / 2 : NPH;
+            int rc;
+            if ((rc = dev_alloc(e, (size_t)4 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
+            if ((rc = dev_alloc(e, (size_t)npp * 4 * 2 * C * KH, &ly.wino_V, wg.allocs, false))) return rc;
+            if ((rc = dev_alloc(e, (size_t)4 * 2 * C, &ly.wino_bias, wg.allocs, false))) return rc;
+            hipLaunchKernelGGL(wino_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
+            hipLaunchKernelGGL(wino_cond_weights_kernel, dim3(blocks_for((long long)npp * 2 * C * KH)), dim3(256), 0, st,
+                               ly.cond_Bt, ly.wino_V, d);
+            hipLaunchKernelGGL(wino_bias_kernel, dim3(blocks_for(2 * C)), dim3(256), 0, st, ly.in_bias, ly.wino_bias);
+            HIPCHK(e, hipGetLastError());
+        }
+    HIPCHK(e, hipStreamSynchronize(st));
+    wg.wino_ready = true;
+    return TTS_HIP_OK;
+}
+
+// Workspace and the mel planes of one call (the mel does not change across layers and flows)
+int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T) {
+    WaveGlowDev& wg = e->wg;
+    hipStream_t st = e->stream;
+    const long long Mh = (long long)(NPH / 2) * PR;
+    HIPCHK(e, wg.wino_U.ensure((size_t)4 * Mh * C * 4));
+    HIPCHK(e, wg.wino_P.ensure((size_t)4 * Mh * 2 * C * 4));
+    // planes for dilations < 32 (rows = PR) and for s = 1, 2, 4 (rows = PR / 2)
+    HIPCHK(e, wg.wino_mel.ensure((size_t)4 * KH * ((size_t)PR + 3 * (size_t)(PR / 2)) * 4));
+    float* base = wg.wino_mel.f();
+    hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base, 0, PR, BT, T);
+    float* p = base + (size_t)4 * PR * KH;
+    for (int s = 1; s <= 4; s *= 2) {
+        hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)(PR / 2) * KH)), dim3(256), 0, st, d_mel, p, s,
+                           PR / 2, BT, T);
+        p += (size_t)4 * (PR / 2) * KH;
+    }
+    HIPCHK(e, hipGetLastError());
+    return TTS_HIP_OK;
+}
+
+// One WN in-layer step (layer i >= 1 of a flow): acts_i = gate(conv_d(x) + cond + b) through the three passes of the header
+int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const float* x, float* acts_i, int PR, int BT, int T) {
+    WaveGlowDev& wg = e->wg;
+    hipStream_t st = e->stream;
+    const int d = 1 << i;
+    const long long Mh = (long long)(NPH / 2) * PR;
+    float* U = wg.wino_U.f();
+    float* P = wg.wino_P.f();
+    hipLaunchKernelGGL(wino_prepass_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mh);
+    GemmArgs g{};
+    g.M = (int)Mh;
+    g.N = 2 * C;
+    g.nseg = 2;
+    const bool pairs_of_phases = d < NPH;
+    g.nphase = pairs_of_phases ? NPH / 2 : NPH;
+    g.phase_rows = pairs_of_phases ? PR : PR / 2;
+    g.frames = pairs_of_phases ? BT : BT / 2;
+    g.L = g.phase_rows;
+    g.phase_step = 0;
+    const float* melP = wg.wino_mel.f();
+    if (!pairs_of_phases) {
+        melP += (size_t)4 * PR * KH;
+        for (int s = 1; s < d / NPH; s *= 2) melP += (size_t)4 * (PR / 2) * KH;
+    }
+    g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mh, 1};
+    g.seg[1] = ASeg{melP, KH, 0, KH, KH, SEG_FRAME_Z, 0, (long long)g.phase_rows, 0};
+    g.Bt = ly.wino_G;
+    g.ldb = C;
+    g.strideBz = (long long)2 * C * C;
+    g.Bt2 = ly.wino_V;
+    g.ldb2 = KH;
+    g.strideB2p = (long long)4 * 2 * C * KH;
+    g.strideB2z = (long long)2 * C * KH;
+    g.bias = ly.wino_bias;
+    g.strideBiasZ = 2 * C;
+    g.mode = EPI_LINEAR;
+    g.act = ACT_NONE;
+    g.split = 2 * C;
+    g.out0 = P;
+    g.ld0 = 2 * C;
+    g.wide_epi = 1;
+    g.strideOutZ = Mh * 2 * C;
+    timing_begin(e, 0);
+    HIPCHK(e, pairs_of_phases ? gemm_wn_wino(g, st) : gemm_wn_wino_128(g, st));
+    timing_end(e);
+    hipLaunchKernelGGL(wino_combine_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, P, acts_i, d, PR, Mh);
+    HIPCHK(e, hipGetLastError());
+    return TTS_HIP_OK;
+}

@@ -420,6 +420,20 @@ class HipEngine:
         """How the last `tacotron2_infer` call ran its loop: 'fused', 'persistent', 'graph', or 'none' before the first call."""
         return {2: 'fused', 1: 'persistent', 0: 'graph'}.get(self._lib.tts_hip_last_decoder_mode(self._h), 'none')
 
+    def set_waveglow_form(self, form: str) -> None:
+        """How the exact-fp32 vocoder evaluates the dilated convolutions of WN layers 1 - 7: 'winograd' (default: F(2,3) along
+        the tap axis whenever the call shape allows it -- 256-row tiles and utterance lengths that are a multiple of 8 frames)
+        or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
+        forms = {'direct': 0, 'winograd': 1}
+        if form not in forms:
+            raise ValueError(f'form must be one of {tuple(forms)}, got {form!r}')
+        self._check(self._lib.tts_hip_set_waveglow_form(self._h, forms[form]), 'set_waveglow_form')
+
+    @property
+    def last_waveglow_form(self) -> str:
+        """'winograd' or 'direct' for the last `waveglow_infer` call on this handle ('none' before the first)."""
+        return {1: 'winograd', 0: 'direct'}.get(self._lib.tts_hip_last_waveglow_form(self._h), 'none')
+
     # ------------------------------------------------------------------ mel-STFT
     def mel_stft(self, audio, stream=None):
         """audio [N] or [B, N] -> mel [B, N // 256 + 1, 80] (the reference's TacotronSTFT()(audio)).  `stream` (torch.cuda.Stream,
