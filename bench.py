@@ -49,6 +49,7 @@ DECODER_STEP_BYTES_F16W = 72.73e6 - 0.5 * (29.36e6 + 41.94e6)   # the two LSTM m
 
 K_EXECUTED = 3 * 512 + 4 * 80      # dilated k3 conv taps + conditioning folded onto 4 mel frames
 K_REFERENCE = 3 * 512 + 640        # the reference formulation: taps + 640-channel upsampled spectrogram
+K_WINOGRAD = 2 * 512 + 4 * 80      # Winograd F(2,3) along the taps (csrc/wn_wino.hip): four K = 512 + 160 products per output PAIR
 
 
 def wn_in_layer_flops(M: int, k: int = K_EXECUTED) -> float:
@@ -414,7 +415,7 @@ def launch_ranks(n: int, argv) -> int:
     return worst
 
 
-def headline_result(args, world, B, T, dt, avg_us, launches, distributed):
+def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='direct'):
     """The JSON line without its secondary parts (CPU baseline, config-4 job, extras), from the timed region's numbers."""
     samples = world * B * T * 256 * args.steps
     M = B * T * 32
@@ -429,16 +430,30 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed):
                     'avg_launch_us': avg_us,
                     'kernel': 'WN in-layer implicit GEMM, fp16 MFMA (' + args.precision + ')'}
     elif launches:
-        achieved = wn_in_layer_flops(M) / (avg_us * 1e-6) / 1e12
+        # `achieved` prices the FLOPs the timed kernel EXECUTES: the Winograd form does K = 1024 + 320 per output (four z
+        # slices of K = 512 + 160 over M / 2 pair rows), the direct form K = 1536 + 320
+        wino = form == 'winograd'
+        k_exec = K_WINOGRAD if wino else K_EXECUTED
+        achieved = wn_in_layer_flops(M, k_exec) / (avg_us * 1e-6) / 1e12
+        if wino:
+            kernel = ('gemm_f32_kernel<4,1,{2|1},4,16,{2|3},TAG_WN_WINO=4,0,PIPE_DMA>, 4 z slices (WN in-layer GEMM of layers 1-7 in '
+                      'its Winograd F(2,3) form: four K = 512 + 160 products on M / 2 pair rows; 256-row tiles for pairs of phases, '
+                      '128-row tiles for pairs of frames; the pre-pass and the combine + gate pass are separate HBM-bound kernels)')
+            # per launch: the four transformed-input planes in, the four product planes out, weights, mel planes
+            alg_bytes = (4 * (M // 2) * 512 + 4 * (M // 2) * 1024 + 4 * 1024 * 512 + 32 * 4 * 1024 * 160 + 4 * B * T * 160) * 4.0
+        else:
+            kernel = ('gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; '
+                      'K = 1536 taps + 320 folded conditioning)')
+            alg_bytes = (M * (512 + 512) + B * T * 80 + 1024 * (1536 + 32 * 320)) * 4.0
         roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                    'flops_per_launch': wn_in_layer_flops(M),
+                    'flops_per_launch': wn_in_layer_flops(M, k_exec),
+                    'direct_formulation_tflops': wn_in_layer_flops(M, K_EXECUTED) / (avg_us * 1e-6) / 1e12,
                     'reference_formulation_tflops': wn_in_layer_flops(M, K_REFERENCE) / (avg_us * 1e-6) / 1e12,
                     'traffic': pmc_traffic_bytes(B, T),
                     'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
-                    'algorithmic_bytes': (M * (512 + 512) + B * T * 80 + 1024 * (1536 + 32 * 320)) * 4.0,
-                    'kernel': 'gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; K = 1536 taps + 320 folded conditioning)', 'launches_timed': launches,
-                    'avg_launch_us': avg_us}
+                    'algorithmic_bytes': alg_bytes, 'in_layer_form': form,
+                    'kernel': kernel, 'launches_timed': launches, 'avg_launch_us': avg_us}
     return {
         'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)' if args.precision == 'f32' else
                   f'audio samples/sec (22.05 kHz WaveGlow vocoding, {args.precision})',
@@ -449,7 +464,7 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed):
                                f'(BASELINE.json configs[1])', 'batch_per_gpu': B, 'mel_frames': T,
                    'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
                    'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
-                   'weights': 'seeded synthetic (rng 1234)'},
+                   'weights': 'seeded synthetic (rng 1234)', 'arithmetic': 'fp32 operands, fp32 MFMA accumulate'},
         'x_realtime': samples / dt / SAMPLE_RATE,
         'roofline': roofline, 'cpu_baseline': None, 'config4_sharded_job': None, 'extra': None,
     }
@@ -552,6 +567,7 @@ def main():
 
     avg_us, launches = (0.0, 0) if args.no_kernel_timing else eng.kernel_time_us(KERNEL_WN_IN)
     eng.kernel_timing(False)
+    form = eng.last_waveglow_form                      # 'winograd' or 'direct': which in-layer GEMM the timed steps ran
     # BASELINE config 4: the scatter / synthesize / gather job, on every rank, at every N.  It must never cost the headline
     # line: an exception is reported inside the line, and a job that does not come back (a rank lost inside a collective
     # leaves the others waiting) is cut off by a watchdog thread that lets rank 0 print the line without it.
@@ -567,7 +583,7 @@ def main():
     if not args.no_config4:
         import threading
         if rank == 0:
-            headline['result'] = headline_result(args, world, B, T, dt, avg_us, launches, distributed)
+            headline['result'] = headline_result(args, world, B, T, dt, avg_us, launches, distributed, form)
             headline['ready'] = True
         watchdog = threading.Timer(CONFIG4_TIMEOUT_S, give_up)
         watchdog.daemon = True
@@ -580,7 +596,7 @@ def main():
     # secondary metrics and the CPU leg only at N = 1 (the other ranks would idle at the final barrier)
     extra = secondary_metrics(eng, dev, rank) if (rank == 0 and world == 1 and not args.no_extra) else None
     if rank == 0:
-        result = headline_result(args, world, B, T, dt, avg_us, launches, distributed)
+        result = headline_result(args, world, B, T, dt, avg_us, launches, distributed, form)
         if args.cpu_frames > 0 and world == 1:
             result['cpu_baseline'] = cpu_baseline(w, cfg, args.cpu_frames)
         result['config4_sharded_job'] = config4
