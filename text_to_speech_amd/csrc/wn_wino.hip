@@ -172,8 +172,8 @@ __global__ void wino_combine_kernel(const float* __restrict__ P, float* __restri
     f32x4 a[4], b[4];
 #pragma unroll
     for (int z = 0; z < 4; ++z) {
-        a[z] = *reinterpret_cast<const f32x4*>(P + z * plane + o);
-        b[z] = *reinterpret_cast<const f32x4*>(P + z * plane + o + 32);
+        a[z] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + z * plane + o));       // read once (371 -> 329 us)
+        b[z] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + z * plane + o + 32));
     }
     const f32x4 t0 = a[0] + a[1] + a[2], s0 = b[0] + b[1] + b[2];
     const f32x4 t1 = a[3] + a[1] - a[2], s1 = b[3] + b[1] - b[2];
