@@ -464,7 +464,11 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                                f'(BASELINE.json configs[1])', 'batch_per_gpu': B, 'mel_frames': T,
                    'audio_seconds_per_step': world * B * T * 256 / SAMPLE_RATE, 'sharding': 'utterances/GPU',
                    'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
-                   'weights': 'seeded synthetic (rng 1234)', 'arithmetic': 'fp32 operands, fp32 MFMA accumulate'},
+                   'weights': 'seeded synthetic (rng 1234)',
+                   'arithmetic': 'fp32 operands, fp32 MFMA accumulate; dilated convolutions of WN layers 1-7 in their '
+                                 + ('Winograd F(2,3) form along the tap axis (csrc/wn_wino.hip; 4.96e-7 waveform RMS error against '
+                                    'the oracle, the direct form 4.96e-7: tests/test_waveglow_gpu.py)' if form == 'winograd'
+                                    else 'direct three-tap form')},
         'x_realtime': samples / dt / SAMPLE_RATE,
         'roofline': roofline, 'cpu_baseline': None, 'config4_sharded_job': None, 'extra': None,
     }
