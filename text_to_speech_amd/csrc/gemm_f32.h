@@ -1117,8 +1117,8 @@ inline hipError_t gemm_wn_in0(const GemmArgs& g, hipStream_t s) { return launch_
 #endif
 inline hipError_t gemm_wn_res_skip(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RES_RT, 4, TTS_WN_BK, TTS_WN_RES_OCC, TAG_WN_RES_SKIP, 0, TTS_WN_PIPE>(g, 1, s); }
 // Winograd form of the in-layer GEMM (wn_wino.hip): four z slices (one per product) on pair rows, K = 512 + 160 each
-inline hipError_t gemm_wn_wino(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_WINO, 0, TTS_WN_PIPE>(g, 4, s); }
-inline hipError_t gemm_wn_wino_128(const GemmArgs& g, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_WINO, 0, TTS_WN_PIPE>(g, 4, s); }
+inline hipError_t gemm_wn_wino(const GemmArgs& g, int nz, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, TTS_WN_RT, 4, TTS_WN_BK, TTS_WN_OCC, TAG_WN_WINO, 0, TTS_WN_PIPE>(g, nz, s); }
+inline hipError_t gemm_wn_wino_128(const GemmArgs& g, int nz, hipStream_t s) { return launch_gemm<TTS_WN_WR, 1, 1, 4, TTS_WN_BK, 3, TAG_WN_WINO, 0, TTS_WN_PIPE>(g, nz, s); }
 inline hipError_t gemm_small(const GemmArgs& g, int bz, hipStream_t s) { return launch_gemm<2, 2, 1, 1, 32, 1, TAG_GENERIC>(g, bz, s); }
 
 }  // namespace ttsgemm

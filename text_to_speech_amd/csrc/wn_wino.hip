@@ -203,6 +203,151 @@ __global__ void wino_combine_kernel(const float* __restrict__ P, float* __restri
     *reinterpret_cast<f32x4*>(acts + r1 * C + ch) = g1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// F(4,3) for the dilations 2, 4, 8 (four outputs l, l + d, l + 2d, l + 3d = four phases of one frame, 8 "group phases"
+// p0 = (gp / d) 4d + gp % d): six K = 512 products per FOUR outputs (K per output 768 instead of 1024 / 1536).  With the six
+// inputs x_i = x[l + (i - 1) d] (Lavin & Gray's F(4,3); fp32 error ~3x the direct form's, far inside the tolerance):
+//   U0 = 4 x0 - 5 x2 + x4            G0 = W- / 4                          y0 = P0 + P1 + P2 + P3 + P4
+//   U1 = -4 x1 - 4 x2 + x3 + x4      G1 = -(W- + W0 + W+) / 6             y1 = P1 - P2 + 2 P3 - 2 P4
+//   U2 = 4 x1 - 4 x2 - x3 + x4       G2 = -(W- - W0 + W+) / 6             y2 = P1 + P2 + 4 P3 + 4 P4
+//   U3 = -2 x1 - x2 + 2 x3 + x4      G3 = W- / 24 + W0 / 12 + W+ / 6      y3 = P1 - P2 + 8 P3 - 8 P4 + P5
+//   U4 = 2 x1 - x2 - 2 x3 + x4       G4 = W- / 24 - W0 / 12 + W+ / 6
+//   U5 = 4 x1 - 5 x3 + x5            G5 = W+
+// The conditioning (same mel rows for the four outputs, four per-phase weight sets V_j) is cut into three K slices, each
+// carried by a product subset whose columns of the output transform have rank 4 -- A = [0, 112) on {0, 1, 2, 5}, B = [112, 208)
+// on {0, 3, 4, 5}, C = [208, 320) on {1, 2, 3, 4} -- with the weights combined by the inverse of those columns, so that every
+// product runs K = 512 + 224 (208 padded to 224 for products 0, 3, 4, 5).  The bias is added in the combine pass.
+constexpr int K4 = 224, SA = 112, SB = 96, SC = 112;       // conditioning K of a product; slice widths (A, B, C)
+
+__device__ __forceinline__ int group_phase0(int gp, int d) { return (gp / d) * 4 * d + gp % d; }
+
+__global__ void wino4_prepass_kernel(const float* __restrict__ x, float* __restrict__ U, int d, int PR, int BT, int T, long long Mq) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mq * (C / 4)) return;
+    const long long mg = idx / (C / 4);
+    const int c = (int)(idx % (C / 4)) * 4;
+    const int gp = (int)(mg / PR);
+    const long long f = mg % PR;
+    const int p0 = group_phase0(gp, d);
+    f32x4 v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = x_at(x, p0 + (i - 1) * d, f, 0, c, PR, BT, T);
+    const long long o = mg * C + c, plane = Mq * C;
+    *reinterpret_cast<f32x4*>(U + o) = 4.f * v[0] - 5.f * v[2] + v[4];
+    *reinterpret_cast<f32x4*>(U + plane + o) = -4.f * (v[1] + v[2]) + v[3] + v[4];
+    *reinterpret_cast<f32x4*>(U + 2 * plane + o) = 4.f * (v[1] - v[2]) - v[3] + v[4];
+    *reinterpret_cast<f32x4*>(U + 3 * plane + o) = 2.f * (v[3] - v[1]) - v[2] + v[4];
+    *reinterpret_cast<f32x4*>(U + 4 * plane + o) = 2.f * (v[1] - v[3]) - v[2] + v[4];
+    *reinterpret_cast<f32x4*>(U + 5 * plane + o) = 4.f * v[1] - 5.f * v[3] + v[5];
+}
+
+__global__ void wino4_weights_kernel(const float* __restrict__ in_Bt, float* __restrict__ G) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * C * C) return;
+    const int n = idx / C, c = idx % C;
+    const float* row = in_Bt + (long long)n * KCONV + (c / 16) * 48 + c % 16;
+    const double wm = row[0], w0 = row[16], wp = row[32];
+    const long long plane = (long long)2 * C * C;
+    G[idx] = (float)(wm / 4.0);
+    G[plane + idx] = (float)(-(wm + w0 + wp) / 6.0);
+    G[2 * plane + idx] = (float)(-(wm - w0 + wp) / 6.0);
+    G[3 * plane + idx] = (float)(wm / 24.0 + w0 / 12.0 + wp / 6.0);
+    G[4 * plane + idx] = (float)(wm / 24.0 - w0 / 12.0 + wp / 6.0);
+    G[5 * plane + idx] = (float)wp;
+}
+
+// coefficient of output j's conditioning weights in product k for a column of slice A / B / C (rows: the subset's products)
+__constant__ double W4_A[4][4] = {{1, 0, -1, 0}, {0, .5, .5, 0}, {0, -.5, .5, 0}, {0, -1, 0, 1}};                      // products 0, 1, 2, 5
+__constant__ double W4_B[4][4] = {{1, 0, -.25, 0}, {0, .25, .125, 0}, {0, -.25, .125, 0}, {0, -4, 0, 1}};               // products 0, 3, 4, 5
+__constant__ double W4_C[4][4] = {{2. / 3, 2. / 3, -1. / 6, -1. / 6}, {2. / 3, -2. / 3, -1. / 6, 1. / 6},
+                                  {-1. / 6, -1. / 12, 1. / 6, 1. / 12}, {-1. / 6, 1. / 12, 1. / 6, -1. / 12}};           // products 1, 2, 3, 4
+
+// V[8][6][1024][224] from cond_Bt [32][1024][320].  Column layout of a product's K = 224: products 0, 5: [A | B | 0 x 16];
+// products 1, 2: [A | C]; products 3, 4: [B | C | 0 x 16]
+__global__ void wino4_cond_weights_kernel(const float* __restrict__ cond_Bt, float* __restrict__ V, int d) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)8 * 6 * 2 * C * K4) return;
+    const int kk = (int)(idx % K4), n = (int)((idx / K4) % (2 * C)), k = (int)((idx / ((long long)K4 * 2 * C)) % 6),
+              gp = (int)(idx / ((long long)K4 * 2 * C * 6));
+    // which slice column, and which row of that slice's coefficient matrix
+    int col = -1, row = 0;
+    const double (*cf)[4] = W4_A;
+    if (k == 0 || k == 5) {
+        if (kk < SA) { col = kk; cf = W4_A; row = k == 0 ? 0 : 3; }
+        else if (kk < SA + SB) { col = SA + (kk - SA); cf = W4_B; row = k == 0 ? 0 : 3; }
+    } else if (k == 1 || k == 2) {
+        if (kk < SA) { col = kk; cf = W4_A; row = k; }
+        else { col = SA + SB + (kk - SA); cf = W4_C; row = k - 1; }
+    } else {
+        if (kk < SB) { col = SA + kk; cf = W4_B; row = k - 2; }
+        else if (kk < SB + SC) { col = SA + SB + (kk - SB); cf = W4_C; row = k - 1; }
+    }
+    double acc = 0.0;
+    if (col >= 0) {
+        const int p0 = group_phase0(gp, d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc += cf[row][j] * (double)cond_Bt[((long long)(p0 + j * d) * 2 * C + n) * KMEL + col];
+    }
+    V[idx] = (float)acc;
+}
+
+// mel planes [6][rows][224] in the column layout above (rows = frames; the same for every group phase)
+__global__ void wino4_mel_planes_kernel(const float* __restrict__ mel, float* __restrict__ P, int rows, int BT, int T) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * K4) return;
+    const long long r = idx / K4;
+    const int kk = (int)(idx % K4);
+    const long long plane = (long long)rows * K4;
+    const float a = kk < SA ? melwin(mel, r, kk, BT, T) : 0.f;                                   // slice A column kk
+    const float b = kk < SB ? melwin(mel, r, SA + kk, BT, T) : 0.f;                              // slice B column kk
+    const float ab = kk < SA ? a : kk < SA + SB ? melwin(mel, r, kk, BT, T) : 0.f;               // [A | B | 0]
+    const float ac = kk < SA ? a : melwin(mel, r, SA + SB + (kk - SA), BT, T);                   // [A | C]
+    const float bc = kk < SB ? b : kk < SB + SC ? melwin(mel, r, SA + SB + (kk - SB), BT, T) : 0.f;   // [B | C | 0]
+    P[idx] = ab;
+    P[plane + idx] = ac;
+    P[2 * plane + idx] = ac;
+    P[3 * plane + idx] = bc;
+    P[4 * plane + idx] = bc;
+    P[5 * plane + idx] = ab;
+}
+
+__global__ void wino4_combine_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ acts, int d,
+                                     int PR, long long Mq) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mq * (C / 4)) return;
+    const long long mg = idx / (C / 4);
+    const int ch = (int)(idx % (C / 4)) * 4;
+    const int col = (ch >> 5) * 64 + (ch & 31);
+    const long long plane = Mq * 2 * C, o = mg * 2 * C + col;
+    f32x4 a[6], b[6];
+#pragma unroll
+    for (int z = 0; z < 6; ++z) {
+        a[z] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + z * plane + o));
+        b[z] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + z * plane + o + 32));
+    }
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + col), bb = *reinterpret_cast<const f32x4*>(bias + col + 32);
+    f32x4 t[4], s[4];
+    t[0] = a[0] + a[1] + a[2] + a[3] + a[4] + ba;
+    t[1] = a[1] - a[2] + 2.f * (a[3] - a[4]) + ba;
+    t[2] = a[1] + a[2] + 4.f * (a[3] + a[4]) + ba;
+    t[3] = a[1] - a[2] + 8.f * (a[3] - a[4]) + a[5] + ba;
+    s[0] = b[0] + b[1] + b[2] + b[3] + b[4] + bb;
+    s[1] = b[1] - b[2] + 2.f * (b[3] - b[4]) + bb;
+    s[2] = b[1] + b[2] + 4.f * (b[3] + b[4]) + bb;
+    s[3] = b[1] - b[2] + 8.f * (b[3] - b[4]) + b[5] + bb;
+    const int gp = (int)(mg / PR);
+    const long long f = mg % PR;
+    const int p0 = group_phase0(gp, d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = gate_tanh_sigmoid(t[j][k], s[j][k]);
+        *reinterpret_cast<f32x4*>(acts + ((long long)(p0 + j * d) * PR + f) * C + ch) = g;
+    }
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
@@ -216,6 +361,15 @@ int waveglow_build_wino(tts_hip_engine* e) {
             WgLayerDev& ly = wg.flow[k].layer[i];
             const int d = 1 << i, npp = d < NPH ? NPH / 2 : NPH;
             int rc;
+            if (d <= 8) {                                  // F(4,3): six products per four outputs
+                if ((rc = dev_alloc(e, (size_t)6 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
+                if ((rc = dev_alloc(e, (size_t)8 * 6 * 2 * C * K4, &ly.wino_V, wg.allocs, false))) return rc;
+                hipLaunchKernelGGL(wino4_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
+                hipLaunchKernelGGL(wino4_cond_weights_kernel, dim3(blocks_for((long long)8 * 6 * 2 * C * K4)), dim3(256), 0, st,
+                                   ly.cond_Bt, ly.wino_V, d);
+                HIPCHK(e, hipGetLastError());
+                continue;
+            }
             if ((rc = dev_alloc(e, (size_t)4 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
             if ((rc = dev_alloc(e, (size_t)npp * 4 * 2 * C * KH, &ly.wino_V, wg.allocs, false))) return rc;
             if ((rc = dev_alloc(e, (size_t)4 * 2 * C, &ly.wino_bias, wg.allocs, false))) return rc;
@@ -238,8 +392,10 @@ int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, i
     HIPCHK(e, wg.wino_U.ensure((size_t)4 * Mh * C * 4));
     HIPCHK(e, wg.wino_P.ensure((size_t)4 * Mh * 2 * C * 4));
     // planes for dilations < 32 (rows = PR) and for s = 1, 2, 4 (rows = PR / 2)
-    HIPCHK(e, wg.wino_mel.ensure((size_t)4 * KH * ((size_t)PR + 3 * (size_t)(PR / 2)) * 4));
+    const size_t mel23 = (size_t)4 * KH * ((size_t)PR + 3 * (size_t)(PR / 2));          // floats of the F(2,3) planes
+    HIPCHK(e, wg.wino_mel.ensure((mel23 + (size_t)6 * PR * K4) * 4));
     float* base = wg.wino_mel.f();
+    hipLaunchKernelGGL(wino4_mel_planes_kernel, dim3(blocks_for((long long)PR * K4)), dim3(256), 0, st, d_mel, base + mel23, PR, BT, T);
     hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base, 0, PR, BT, T);
     float* p = base + (size_t)4 * PR * KH;
     for (int s = 1; s <= 4; s *= 2) {
@@ -259,6 +415,41 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     const long long Mh = (long long)(NPH / 2) * PR;
     float* U = wg.wino_U.f();
     float* P = wg.wino_P.f();
+    if (d <= 8) {                                          // F(4,3) on groups of four phases
+        const long long Mq = (long long)(NPH / 4) * PR;
+        hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
+        GemmArgs g{};
+        g.M = (int)Mq;
+        g.N = 2 * C;
+        g.nseg = 2;
+        g.nphase = NPH / 4;
+        g.phase_rows = PR;
+        g.frames = BT;
+        g.L = PR;
+        const float* mel6 = wg.wino_mel.f() + (size_t)4 * KH * ((size_t)PR + 3 * (size_t)(PR / 2));
+        g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mq, 1};
+        g.seg[1] = ASeg{mel6, K4, 0, K4, K4, SEG_FRAME_Z, 0, (long long)PR, 0};
+        g.Bt = ly.wino_G;
+        g.ldb = C;
+        g.strideBz = (long long)2 * C * C;
+        g.Bt2 = ly.wino_V;
+        g.ldb2 = K4;
+        g.strideB2p = (long long)6 * 2 * C * K4;
+        g.strideB2z = (long long)2 * C * K4;
+        g.mode = EPI_LINEAR;
+        g.act = ACT_NONE;
+        g.split = 2 * C;
+        g.out0 = P;
+        g.ld0 = 2 * C;
+        g.wide_epi = 1;
+        g.strideOutZ = Mq * 2 * C;
+        timing_begin(e, 0);
+        HIPCHK(e, gemm_wn_wino(g, 6, st));
+        timing_end(e);
+        hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, Mq);
+        HIPCHK(e, hipGetLastError());
+        return TTS_HIP_OK;
+    }
     hipLaunchKernelGGL(wino_prepass_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mh);
     GemmArgs g{};
     g.M = (int)Mh;
@@ -294,7 +485,7 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     g.wide_epi = 1;
     g.strideOutZ = Mh * 2 * C;
     timing_begin(e, 0);
-    HIPCHK(e, pairs_of_phases ? gemm_wn_wino(g, st) : gemm_wn_wino_128(g, st));
+    HIPCHK(e, pairs_of_phases ? gemm_wn_wino(g, 4, st) : gemm_wn_wino_128(g, 4, st));
     timing_end(e);
     hipLaunchKernelGGL(wino_combine_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, P, acts_i, d, PR, Mh);
     HIPCHK(e, hipGetLastError());
