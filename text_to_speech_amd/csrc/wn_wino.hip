@@ -27,6 +27,8 @@
 #include "engine.h"
 #include "gemm_f32.h"
 
+#include <algorithm>
+
 using namespace ttsgemm;
 
 namespace {
@@ -226,12 +228,21 @@ __global__ void wino4_prepass_kernel(const float* __restrict__ x, float* __restr
     if (idx >= Mq * (C / 4)) return;
     const long long mg = idx / (C / 4);
     const int c = (int)(idx % (C / 4)) * 4;
-    const int gp = (int)(mg / PR);
-    const long long f = mg % PR;
-    const int p0 = group_phase0(gp, d);
     f32x4 v[6];
+    if (d < NPH) {                                         // four phases of one frame
+        const int gp = (int)(mg / PR);
+        const long long f = mg % PR;
+        const int p0 = group_phase0(gp, d);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = x_at(x, p0 + (i - 1) * d, f, 0, c, PR, BT, T);
+        for (int i = 0; i < 6; ++i) v[i] = x_at(x, p0 + (i - 1) * d, f, 0, c, PR, BT, T);
+    } else {                                               // four frames f0 + j s of one phase (PRq group rows per phase)
+        const int s = d / NPH, PRq = (int)(Mq / NPH);
+        const int p = (int)(mg / PRq);
+        const long long gf = mg % PRq;
+        const long long f0 = (gf / s) * 4 * s + gf % s;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = x_at(x, p, f0, (i - 1) * s, c, PR, BT, T);
+    }
     const long long o = mg * C + c, plane = Mq * C;
     *reinterpret_cast<f32x4*>(U + o) = 4.f * v[0] - 5.f * v[2] + v[4];
     *reinterpret_cast<f32x4*>(U + plane + o) = -4.f * (v[1] + v[2]) + v[3] + v[4];
@@ -312,6 +323,56 @@ __global__ void wino4_mel_planes_kernel(const float* __restrict__ mel, float* __
     P[5 * plane + idx] = ab;
 }
 
+// which slice column a product's conditioning column kk is (-1: padding) and the row of the slice's coefficient matrix
+__device__ __forceinline__ int slice_col(int k, int kk, int& row, int& which) {
+    if (k == 0 || k == 5) {
+        row = k == 0 ? 0 : 3;
+        if (kk < SA) { which = 0; return kk; }
+        if (kk < SA + SB) { which = 1; return kk; }
+    } else if (k == 1 || k == 2) {
+        if (kk < SA) { which = 0; row = k; return kk; }
+        which = 2;
+        row = k - 1;
+        return SA + SB + (kk - SA);
+    } else {
+        if (kk < SB) { which = 1; row = k - 2; return SA + kk; }
+        if (kk < SB + SC) { which = 2; row = k - 1; return SA + SB + (kk - SB); }
+    }
+    which = 0;
+    return -1;
+}
+
+// dilations >= 32 (four FRAMES of one phase): the four outputs share the weights, so the products' weights are plain column
+// selections V[32][6][1024][224] of V_p in the column layout above, and the slice combinations are formed on the mel side
+__global__ void wino4_cond_weights_frames_kernel(const float* __restrict__ cond_Bt, float* __restrict__ V) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)NPH * 6 * 2 * C * K4) return;
+    const int kk = (int)(idx % K4), n = (int)((idx / K4) % (2 * C)), k = (int)((idx / ((long long)K4 * 2 * C)) % 6),
+              p = (int)(idx / ((long long)K4 * 2 * C * 6));
+    int row, which;
+    const int col = slice_col(k, kk, row, which);
+    V[idx] = col >= 0 ? cond_Bt[((long long)p * 2 * C + n) * KMEL + col] : 0.f;
+}
+
+// mel planes [6][rows][224] for s = d / 32: row gf <-> frames f_j = (gf / s) 4 s + gf % s + j s; product k, slice column:
+// sum_j coef[k][j] melwin(f_j)
+__global__ void wino4_mel_planes_frames_kernel(const float* __restrict__ mel, float* __restrict__ P, int s, int rows, int BT, int T) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)6 * rows * K4) return;
+    const int kk = (int)(idx % K4), k = (int)(idx / ((long long)rows * K4));
+    const long long gf = (idx / K4) % rows;
+    const long long f0 = (gf / s) * 4 * s + gf % s;
+    int row, which;
+    const int col = slice_col(k, kk, row, which);
+    double acc = 0.0;
+    if (col >= 0) {
+        const double (*cf)[4] = which == 0 ? W4_A : which == 1 ? W4_B : W4_C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += cf[row][j] * (double)melwin(mel, f0 + j * s, col, BT, T);
+    }
+    P[idx] = (float)acc;
+}
+
 __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ acts, int d,
                                      int PR, long long Mq) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,15 +397,26 @@ __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* _
     s[1] = b[1] - b[2] + 2.f * (b[3] - b[4]) + bb;
     s[2] = b[1] + b[2] + 4.f * (b[3] + b[4]) + bb;
     s[3] = b[1] - b[2] + 8.f * (b[3] - b[4]) + b[5] + bb;
-    const int gp = (int)(mg / PR);
-    const long long f = mg % PR;
-    const int p0 = group_phase0(gp, d);
+    long long r0, rstep;                                   // acts row of output 0 and the row step between outputs
+    if (d < NPH) {
+        const int gp = (int)(mg / PR);
+        r0 = (long long)group_phase0(gp, d) * PR + mg % PR;
+        rstep = (long long)d * PR;
+    } else {
+        const int sf = d / NPH, PRq = (int)(Mq / NPH);
+        const int p = (int)(mg / PRq);
+        const long long gf = mg % PRq;
+        const long long f0 = (gf / sf) * 4 * sf + gf % sf;
+        if (f0 + 3 * sf >= PR) return;                     // padding group rows past the phase block
+        r0 = (long long)p * PR + f0;
+        rstep = sf;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 g;
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = gate_tanh_sigmoid(t[j][k], s[j][k]);
-        *reinterpret_cast<f32x4*>(acts + ((long long)(p0 + j * d) * PR + f) * C + ch) = g;
+        *reinterpret_cast<f32x4*>(acts + (r0 + j * rstep) * C + ch) = g;
     }
 }
 
@@ -352,6 +424,9 @@ inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 // Per-layer operands (once, on the first call that takes this path): G, V and the bias planes of layers 1 .. 7 of every flow
+// group rows per phase block of the frame-group layers (dilations >= 32): PR / 4, padded to the 128-row tile
+static inline int frame_group_rows(int PR) { return (PR / 4 + 127) / 128 * 128; }
+
 int waveglow_build_wino(tts_hip_engine* e) {
     WaveGlowDev& wg = e->wg;
     if (wg.wino_ready) return TTS_HIP_OK;
@@ -359,22 +434,28 @@ int waveglow_build_wino(tts_hip_engine* e) {
     for (int k = 0; k < 12; ++k)
         for (int i = 1; i < 8; ++i) {
             WgLayerDev& ly = wg.flow[k].layer[i];
-            const int d = 1 << i, npp = d < NPH ? NPH / 2 : NPH;
+            const int d = 1 << i;
             int rc;
-            if (d <= 8) {                                  // F(4,3): six products per four outputs
+            if (d != 16) {                                 // F(4,3): six products per four outputs
+                const int ngp = d < NPH ? NPH / 4 : NPH;   // weight sets: group phases, or phases
                 if ((rc = dev_alloc(e, (size_t)6 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
-                if ((rc = dev_alloc(e, (size_t)8 * 6 * 2 * C * K4, &ly.wino_V, wg.allocs, false))) return rc;
+                if ((rc = dev_alloc(e, (size_t)ngp * 6 * 2 * C * K4, &ly.wino_V, wg.allocs, false))) return rc;
                 hipLaunchKernelGGL(wino4_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
-                hipLaunchKernelGGL(wino4_cond_weights_kernel, dim3(blocks_for((long long)8 * 6 * 2 * C * K4)), dim3(256), 0, st,
-                                   ly.cond_Bt, ly.wino_V, d);
+                if (d < NPH)
+                    hipLaunchKernelGGL(wino4_cond_weights_kernel, dim3(blocks_for((long long)ngp * 6 * 2 * C * K4)), dim3(256), 0,
+                                       st, ly.cond_Bt, ly.wino_V, d);
+                else
+                    hipLaunchKernelGGL(wino4_cond_weights_frames_kernel, dim3(blocks_for((long long)ngp * 6 * 2 * C * K4)),
+                                       dim3(256), 0, st, ly.cond_Bt, ly.wino_V);
                 HIPCHK(e, hipGetLastError());
                 continue;
             }
+            // d = 16: the four outputs would be two phases x two frames, sharing neither mel rows nor weights -> F(2,3)
             if ((rc = dev_alloc(e, (size_t)4 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
-            if ((rc = dev_alloc(e, (size_t)npp * 4 * 2 * C * KH, &ly.wino_V, wg.allocs, false))) return rc;
+            if ((rc = dev_alloc(e, (size_t)(NPH / 2) * 4 * 2 * C * KH, &ly.wino_V, wg.allocs, false))) return rc;
             if ((rc = dev_alloc(e, (size_t)4 * 2 * C, &ly.wino_bias, wg.allocs, false))) return rc;
             hipLaunchKernelGGL(wino_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
-            hipLaunchKernelGGL(wino_cond_weights_kernel, dim3(blocks_for((long long)npp * 2 * C * KH)), dim3(256), 0, st,
+            hipLaunchKernelGGL(wino_cond_weights_kernel, dim3(blocks_for((long long)(NPH / 2) * 2 * C * KH)), dim3(256), 0, st,
                                ly.cond_Bt, ly.wino_V, d);
             hipLaunchKernelGGL(wino_bias_kernel, dim3(blocks_for(2 * C)), dim3(256), 0, st, ly.in_bias, ly.wino_bias);
             HIPCHK(e, hipGetLastError());
@@ -384,25 +465,38 @@ int waveglow_build_wino(tts_hip_engine* e) {
     return TTS_HIP_OK;
 }
 
+// Layout of the per-call mel planes (floats): [F(2,3): 4][PR][160] | [F(4,3) phases: 6][PR][224] | 3 x [F(4,3) frames: 6][PRq][224]
+struct MelPlanes {
+    size_t f23, f43p, f43f[3], total;
+    MelPlanes(int PR) {
+        const size_t PRq = (size_t)frame_group_rows(PR);
+        f23 = 0;
+        f43p = (size_t)4 * PR * KH;
+        f43f[0] = f43p + (size_t)6 * PR * K4;
+        f43f[1] = f43f[0] + 6 * PRq * K4;
+        f43f[2] = f43f[1] + 6 * PRq * K4;
+        total = f43f[2] + 6 * PRq * K4;
+    }
+};
+
 // Workspace and the mel planes of one call (the mel does not change across layers and flows)
 int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T) {
     WaveGlowDev& wg = e->wg;
     hipStream_t st = e->stream;
     const long long Mh = (long long)(NPH / 2) * PR;
-    HIPCHK(e, wg.wino_U.ensure((size_t)4 * Mh * C * 4));
-    HIPCHK(e, wg.wino_P.ensure((size_t)4 * Mh * 2 * C * 4));
-    // planes for dilations < 32 (rows = PR) and for s = 1, 2, 4 (rows = PR / 2)
-    const size_t mel23 = (size_t)4 * KH * ((size_t)PR + 3 * (size_t)(PR / 2));          // floats of the F(2,3) planes
-    HIPCHK(e, wg.wino_mel.ensure((mel23 + (size_t)6 * PR * K4) * 4));
+    const int PRq = frame_group_rows(PR);
+    // U / P planes: F(2,3) 4 x (16 PR) rows, F(4,3) phases 6 x (8 PR), F(4,3) frames 6 x (32 PRq)
+    const size_t rows = (size_t)std::max<long long>(4 * Mh, (long long)6 * NPH * PRq);
+    HIPCHK(e, wg.wino_U.ensure(rows * C * 4));
+    HIPCHK(e, wg.wino_P.ensure(rows * 2 * C * 4));
+    const MelPlanes mp(PR);
+    HIPCHK(e, wg.wino_mel.ensure(mp.total * 4));
     float* base = wg.wino_mel.f();
-    hipLaunchKernelGGL(wino4_mel_planes_kernel, dim3(blocks_for((long long)PR * K4)), dim3(256), 0, st, d_mel, base + mel23, PR, BT, T);
-    hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base, 0, PR, BT, T);
-    float* p = base + (size_t)4 * PR * KH;
-    for (int s = 1; s <= 4; s *= 2) {
-        hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)(PR / 2) * KH)), dim3(256), 0, st, d_mel, p, s,
-                           PR / 2, BT, T);
-        p += (size_t)4 * (PR / 2) * KH;
-    }
+    hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base + mp.f23, 0, PR, BT, T);
+    hipLaunchKernelGGL(wino4_mel_planes_kernel, dim3(blocks_for((long long)PR * K4)), dim3(256), 0, st, d_mel, base + mp.f43p, PR, BT, T);
+    for (int si = 0; si < 3; ++si)
+        hipLaunchKernelGGL(wino4_mel_planes_frames_kernel, dim3(blocks_for((long long)6 * PRq * K4)), dim3(256), 0, st, d_mel,
+                           base + mp.f43f[si], 1 << si, PRq, BT, T);
     HIPCHK(e, hipGetLastError());
     return TTS_HIP_OK;
 }
@@ -412,80 +506,64 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     WaveGlowDev& wg = e->wg;
     hipStream_t st = e->stream;
     const int d = 1 << i;
-    const long long Mh = (long long)(NPH / 2) * PR;
     float* U = wg.wino_U.f();
     float* P = wg.wino_P.f();
-    if (d <= 8) {                                          // F(4,3) on groups of four phases
-        const long long Mq = (long long)(NPH / 4) * PR;
-        hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
-        GemmArgs g{};
-        g.M = (int)Mq;
-        g.N = 2 * C;
-        g.nseg = 2;
-        g.nphase = NPH / 4;
-        g.phase_rows = PR;
-        g.frames = BT;
-        g.L = PR;
-        const float* mel6 = wg.wino_mel.f() + (size_t)4 * KH * ((size_t)PR + 3 * (size_t)(PR / 2));
-        g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mq, 1};
-        g.seg[1] = ASeg{mel6, K4, 0, K4, K4, SEG_FRAME_Z, 0, (long long)PR, 0};
-        g.Bt = ly.wino_G;
-        g.ldb = C;
-        g.strideBz = (long long)2 * C * C;
-        g.Bt2 = ly.wino_V;
-        g.ldb2 = K4;
-        g.strideB2p = (long long)6 * 2 * C * K4;
-        g.strideB2z = (long long)2 * C * K4;
-        g.mode = EPI_LINEAR;
-        g.act = ACT_NONE;
-        g.split = 2 * C;
-        g.out0 = P;
-        g.ld0 = 2 * C;
-        g.wide_epi = 1;
-        g.strideOutZ = Mq * 2 * C;
-        timing_begin(e, 0);
-        HIPCHK(e, gemm_wn_wino(g, 6, st));
-        timing_end(e);
-        hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, Mq);
-        HIPCHK(e, hipGetLastError());
-        return TTS_HIP_OK;
-    }
-    hipLaunchKernelGGL(wino_prepass_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mh);
+    const MelPlanes mp(PR);
     GemmArgs g{};
-    g.M = (int)Mh;
     g.N = 2 * C;
     g.nseg = 2;
-    const bool pairs_of_phases = d < NPH;
-    g.nphase = pairs_of_phases ? NPH / 2 : NPH;
-    g.phase_rows = pairs_of_phases ? PR : PR / 2;
-    g.frames = pairs_of_phases ? BT : BT / 2;
-    g.L = g.phase_rows;
-    g.phase_step = 0;
-    const float* melP = wg.wino_mel.f();
-    if (!pairs_of_phases) {
-        melP += (size_t)4 * PR * KH;
-        for (int s = 1; s < d / NPH; s *= 2) melP += (size_t)4 * (PR / 2) * KH;
-    }
-    g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mh, 1};
-    g.seg[1] = ASeg{melP, KH, 0, KH, KH, SEG_FRAME_Z, 0, (long long)g.phase_rows, 0};
     g.Bt = ly.wino_G;
     g.ldb = C;
     g.strideBz = (long long)2 * C * C;
     g.Bt2 = ly.wino_V;
-    g.ldb2 = KH;
-    g.strideB2p = (long long)4 * 2 * C * KH;
-    g.strideB2z = (long long)2 * C * KH;
-    g.bias = ly.wino_bias;
-    g.strideBiasZ = 2 * C;
     g.mode = EPI_LINEAR;
     g.act = ACT_NONE;
     g.split = 2 * C;
     g.out0 = P;
     g.ld0 = 2 * C;
     g.wide_epi = 1;
+    if (d != 16) {                                         // F(4,3): groups of four phases (d <= 8) or of four frames (d >= 32)
+        const bool phases = d < NPH;
+        const int PRq = frame_group_rows(PR);
+        const long long Mq = phases ? (long long)(NPH / 4) * PR : (long long)NPH * PRq;
+        hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
+        g.M = (int)Mq;
+        g.nphase = phases ? NPH / 4 : NPH;
+        g.phase_rows = phases ? PR : PRq;
+        g.frames = phases ? BT : BT / 4;
+        g.L = g.phase_rows;
+        const float* mel6 = wg.wino_mel.f() + (phases ? mp.f43p : mp.f43f[i - 5]);
+        g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mq, 1};
+        g.seg[1] = ASeg{mel6, K4, 0, K4, K4, SEG_FRAME_Z, 0, (long long)g.phase_rows, 0};
+        g.ldb2 = K4;
+        g.strideB2p = (long long)6 * 2 * C * K4;
+        g.strideB2z = (long long)2 * C * K4;
+        g.strideOutZ = Mq * 2 * C;
+        timing_begin(e, 0);
+        HIPCHK(e, phases ? gemm_wn_wino(g, 6, st) : gemm_wn_wino_128(g, 6, st));
+        timing_end(e);
+        hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, Mq);
+        HIPCHK(e, hipGetLastError());
+        return TTS_HIP_OK;
+    }
+    // d = 16: F(2,3) on pairs of phases (p0, p0 + 16)
+    const long long Mh = (long long)(NPH / 2) * PR;
+    hipLaunchKernelGGL(wino_prepass_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mh);
+    g.M = (int)Mh;
+    g.nphase = NPH / 2;
+    g.phase_rows = PR;
+    g.frames = BT;
+    g.L = PR;
+    g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mh, 1};
+    g.seg[1] = ASeg{wg.wino_mel.f() + mp.f23, KH, 0, KH, KH, SEG_FRAME_Z, 0, (long long)PR, 0};
+    g.ldb2 = KH;
+    g.strideB2p = (long long)4 * 2 * C * KH;
+    g.strideB2z = (long long)2 * C * KH;
+    g.bias = ly.wino_bias;
+    g.strideBiasZ = 2 * C;
     g.strideOutZ = Mh * 2 * C;
     timing_begin(e, 0);
-    HIPCHK(e, pairs_of_phases ? gemm_wn_wino(g, 4, st) : gemm_wn_wino_128(g, 4, st));
+    HIPCHK(e, gemm_wn_wino(g, 4, st));
     timing_end(e);
     hipLaunchKernelGGL(wino_combine_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, P, acts_i, d, PR, Mh);
     HIPCHK(e, hipGetLastError());
