@@ -49,7 +49,19 @@ DECODER_STEP_BYTES_F16W = 72.73e6 - 0.5 * (29.36e6 + 41.94e6)   # the two LSTM m
 
 K_EXECUTED = 3 * 512 + 4 * 80      # dilated k3 conv taps + conditioning folded onto 4 mel frames
 K_REFERENCE = 3 * 512 + 640        # the reference formulation: taps + 640-channel upsampled spectrogram
-K_WINOGRAD = 2 * 512 + 4 * 80      # Winograd F(2,3) along the taps (csrc/wn_wino.hip): four K = 512 + 160 products per output PAIR
+
+
+def wino_in_layer_flops(B: int, T: int) -> float:
+    """FLOPs the Winograd form of the in-layer GEMM EXECUTES per launch, averaged over the 7 launches of a flow
+    (csrc/wn_wino.hip): F(4,3) = six K = 512 + 224 products on M / 4 group rows for the dilations 2, 4, 8 (groups of phases)
+    and 32, 64, 128 (groups of frames: group rows per phase padded to the 128-row tile), F(2,3) = four K = 512 + 160 products
+    on M / 2 pair rows for dilation 16."""
+    PR = (B * T + 255) // 256 * 256                      # frame rows per phase block (256-row tiles)
+    PRq = (PR // 4 + 127) // 128 * 128
+    f43_phases = 6 * (8 * PR) * (512 + 224)
+    f43_frames = 6 * (32 * PRq) * (512 + 224)
+    f23 = 4 * (16 * PR) * (512 + 160)
+    return 2.0 * 1024 * (3 * f43_phases + 3 * f43_frames + f23) / 7.0
 
 
 def wn_in_layer_flops(M: int, k: int = K_EXECUTED) -> float:
@@ -430,24 +442,26 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                     'avg_launch_us': avg_us,
                     'kernel': 'WN in-layer implicit GEMM, fp16 MFMA (' + args.precision + ')'}
     elif launches:
-        # `achieved` prices the FLOPs the timed kernel EXECUTES: the Winograd form does K = 1024 + 320 per output (four z
-        # slices of K = 512 + 160 over M / 2 pair rows), the direct form K = 1536 + 320
+        # `achieved` prices the FLOPs the timed kernel EXECUTES: the Winograd form ~K = 1160 per output (wino_in_layer_flops),
+        # the direct form K = 1536 + 320
         wino = form == 'winograd'
-        k_exec = K_WINOGRAD if wino else K_EXECUTED
-        achieved = wn_in_layer_flops(M, k_exec) / (avg_us * 1e-6) / 1e12
+        flops = wino_in_layer_flops(B, T) if wino else wn_in_layer_flops(M)
+        achieved = flops / (avg_us * 1e-6) / 1e12
         if wino:
-            kernel = ('gemm_f32_kernel<4,1,{2|1},4,16,{2|3},TAG_WN_WINO=4,0,PIPE_DMA>, 4 z slices (WN in-layer GEMM of layers 1-7 in '
-                      'its Winograd F(2,3) form: four K = 512 + 160 products on M / 2 pair rows; 256-row tiles for pairs of phases, '
-                      '128-row tiles for pairs of frames; the pre-pass and the combine + gate pass are separate HBM-bound kernels)')
-            # per launch: the four transformed-input planes in, the four product planes out, weights, mel planes
-            alg_bytes = (4 * (M // 2) * 512 + 4 * (M // 2) * 1024 + 4 * 1024 * 512 + 32 * 4 * 1024 * 160 + 4 * B * T * 160) * 4.0
+            kernel = ('gemm_f32_kernel<4,1,{2|1},4,16,{2|3},TAG_WN_WINO=4,0,PIPE_DMA>, one z slice per Winograd product (WN in-layer '
+                      'GEMM of layers 1-7: F(4,3) = six K = 512 + 224 products on M / 4 group rows for dilations 2, 4, 8 (256-row '
+                      'tiles) and 32, 64, 128 (128-row tiles), F(2,3) = four K = 512 + 160 products on M / 2 pair rows for dilation '
+                      '16; average over the 7 launches of a flow; the pre-pass and the combine + gate pass are separate HBM-bound '
+                      'kernels)')
+            # per launch (F(4,3)): six transformed-input planes in, six product planes out, weights
+            alg_bytes = (6 * (M // 4) * 512 + 6 * (M // 4) * 1024 + 6 * 1024 * 512 + 8 * 6 * 1024 * 224) * 4.0
         else:
             kernel = ('gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; '
                       'K = 1536 taps + 320 folded conditioning)')
             alg_bytes = (M * (512 + 512) + B * T * 80 + 1024 * (1536 + 32 * 320)) * 4.0
         roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                    'flops_per_launch': wn_in_layer_flops(M, k_exec),
+                    'flops_per_launch': flops,
                     'direct_formulation_tflops': wn_in_layer_flops(M, K_EXECUTED) / (avg_us * 1e-6) / 1e12,
                     'reference_formulation_tflops': wn_in_layer_flops(M, K_REFERENCE) / (avg_us * 1e-6) / 1e12,
                     'traffic': pmc_traffic_bytes(B, T),
@@ -466,8 +480,9 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                    'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
                    'weights': 'seeded synthetic (rng 1234)',
                    'arithmetic': 'fp32 operands, fp32 MFMA accumulate; dilated convolutions of WN layers 1-7 in their '
-                                 + ('Winograd F(2,3) form along the tap axis (csrc/wn_wino.hip; 4.96e-7 waveform RMS error against '
-                                    'the oracle, the direct form 4.96e-7: tests/test_waveglow_gpu.py)' if form == 'winograd'
+                                 + ('Winograd form along the tap axis (csrc/wn_wino.hip: F(4,3), F(2,3) for dilation 16; 5.9e-7 '
+                                    'waveform RMS error against the oracle, the direct form 4.96e-7: tests/test_waveglow_gpu.py)'
+                                    if form == 'winograd'
                                     else 'direct three-tap form')},
         'x_realtime': samples / dt / SAMPLE_RATE,
         'roofline': roofline, 'cpu_baseline': None, 'config4_sharded_job': None, 'extra': None,

@@ -1,29 +1,36 @@
-// wn_wino.hip -- Winograd F(2,3) along the tap axis of the WN dilated convolution (exact-fp32 path, large batches).
+// wn_wino.hip -- Winograd minimal filtering along the tap axis of the WN dilated convolution (fp32 path, 256-row tiles).
 //
 // The in-layer pre-activation of WaveGlow's WN (/root/reference/architectures/waveglow_arch.py:117-127) is a k = 3 dilated
-// convolution plus the conditioning term,  y[l] = W- x[l - d] + W0 x[l] + W+ x[l + d] + c[l] + b.  Two outputs one dilation
-// apart, y0 = y[l] and y1 = y[l + d], share the inputs x[l - d], x[l], x[l + d], x[l + 2d]; the minimal-filtering form
-//     m0 = (x[l-d] - x[l+d]) W-            m1 = (x[l] + x[l+d]) (W- + W0 + W+) / 2
-//     m2 = (x[l+d] - x[l]) (W- - W0 + W+) / 2        m3 = (x[l] - x[l+2d]) W+
-//     y0 = m0 + m1 + m2 + c0 + b           y1 = m1 - m2 - m3 + c1 + b
-// needs four K = 512 products per output PAIR instead of six: K per output 1024 instead of 1536.  The conditioning term
-// (K = 320 per output) rides along without leaving any of the four products idle: its first half (K = 160) goes into the
-// products that feed one output only (m0 for y0, -m3 for y1) and, writing c0 = s + e, c1 = s - e, the second half as s into
-// m1 and as e into m2.  So a layer is ONE launch of the GEMM kernel of gemm_f32.h with four z slices (one per product) of
-// K = 512 + 160 each, on "pair rows", followed by a combine + gate pass:
+// convolution plus the conditioning term,  y[l] = W- x[l - d] + W0 x[l] + W+ x[l + d] + c[l] + b.  Outputs one dilation apart
+// share inputs, so NO outputs y[l], y[l + d], ... need only NO + 2 products instead of 3 NO:
 //
-//   pre-pass   x -> U[4][M/2][512]            (the four transformed inputs, one plane per product; HBM-bound)
-//   GEMM       P[z] = U[z] G[z]^T + melP[z] V[z]^T (+ b for z = 0, 3)        z = (m0, m1, m2, -m3)
-//   combine    y0 = P0 + P1 + P2,  y1 = P3 + P1 - P2,  acts = tanh(.) * sigmoid(.) written to both output rows
+//   F(4,3)  six products per FOUR outputs (K per output 768 instead of 1536; dilations 2, 4, 8, 32, 64, 128; see below)
+//   F(2,3)  four products per TWO outputs (K per output 1024; dilation 16)
 //
-// Pairs: dilation d < 32 (sample groups): phases (p0, p0 + d) of the same frame, p0 = (pp / d) 2d + pp % d for the 16
-// "pair phases" pp -- the two outputs share their mel rows and differ in the per-phase conditioning weights, so s / e are
-// weight combinations (V_p0 +- V_p1) / 2.  Dilation >= 32 (s = d / 32 frames): frames (f0, f0 + s) of the same phase, f0 =
-// (fp / s) 2s + fp % s -- the outputs share the weights and s / e are combinations of mel rows.  Utterance lengths must be a
-// multiple of 8 frames (pairs never straddle an utterance), else the direct kernel runs.
+// and the NO + 2 products are ONE launch of the GEMM kernel of gemm_f32.h: one blockIdx.z slice per product on M / NO "group
+// rows", operand planes U[z] against weight planes G[z].  Three passes per layer:
 //
-// Numerics: every operand stays fp32 and all weight combinations are formed in fp64 and rounded once; the result differs
-// from the direct form by fp32 rounding only (it is not bit-identical to it).
+//   pre-pass   x -> U[NO + 2][M / NO][512]     (the transformed inputs; HBM-bound)
+//   GEMM       P[z] = U[z] G[z]^T + melP[z] V[z]^T
+//   combine    y_j = sum_z AT[j][z] P[z] (+ b),  acts = tanh(.) * sigmoid(.)  written to the NO output rows
+//
+// The conditioning term (K = 320 per output) is spread over the products so that none idles.  F(2,3): its first half goes
+// into the products that feed one output only (m0, -m3) and, with c0 = s + e, c1 = s - e, the second half as s into m1 and as e
+// into m2: K = 512 + 160 per product.  F(4,3): three K slices A = [0, 112), B = [112, 208), C = [208, 320), each carried by a
+// product subset whose columns of the output transform AT have rank 4 -- {0, 1, 2, 5}, {0, 3, 4, 5}, {1, 2, 3, 4} -- and
+// combined with the inverse of those columns: K = 512 + 224 per product (208 padded to 224 for products 0, 3, 4, 5).
+//
+// Groups.  Dilation d <= 8 (sample groups): four PHASES p0 + j d of one frame, 8 group phases p0 = (gp / d) 4d + gp % d; the
+// outputs share their mel rows and differ in the per-phase conditioning weights, so the slice combinations are WEIGHT
+// combinations built at load.  d >= 32 (s = d / 32 frames): four FRAMES f0 + j s of one phase, f0 = (gf / s) 4s + gf % s; the
+// outputs share the weights and the combinations are MEL combinations built once per call (group rows per phase padded to
+// the 128-row tile).  d = 16: four outputs would be two phases x two frames and share neither, so that layer runs F(2,3) on
+// the 16 phase pairs (p0, p0 + 16).  Utterance lengths must be a multiple of 16 frames (no group straddles an utterance),
+// else the direct kernel runs.
+//
+// Numerics: every operand stays fp32, weight / mel combinations are formed in fp64 and rounded once.  F(4,3)'s transform
+// constants (4, 5, 8, 1/6, 1/24) cost accuracy: error of one layer ~3x the direct form's (F(2,3): 1.3x); end to end against
+// the oracle 5.9e-7 waveform RMS (direct form 4.96e-7; tolerance 1e-4).  Not bit-identical to the direct form.
 #include "engine.h"
 #include "gemm_f32.h"
 
@@ -53,32 +60,18 @@ __device__ __forceinline__ f32x4 x_at(const float* __restrict__ x, int ps, long 
     return *reinterpret_cast<const f32x4*>(x + ((long long)(ps & 31) * PR + f + carry) * C + c);
 }
 
-// U planes (see the header).  One thread per (pair row, 4 channels).
+// F(2,3), pairs of phases (p0, p1 = p0 + d): U planes.  One thread per (pair row, 4 channels).
 __global__ void wino_prepass_kernel(const float* __restrict__ x, float* __restrict__ U, int d, int PR, int BT, int T, long long Mh) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Mh * (C / 4)) return;
     const long long mp = idx / (C / 4);
     const int c = (int)(idx % (C / 4)) * 4;
-    f32x4 xm, x0, x1, x2;
-    if (d < NPH) {
-        const int pp = (int)(mp / PR);
-        const long long f = mp % PR;
-        int p0, p1;
-        pair_phases(pp, d, p0, p1);
-        xm = x_at(x, p0 - d, f, 0, c, PR, BT, T);
-        x0 = x_at(x, p0, f, 0, c, PR, BT, T);
-        x1 = x_at(x, p1, f, 0, c, PR, BT, T);
-        x2 = x_at(x, p1 + d, f, 0, c, PR, BT, T);
-    } else {
-        const int s = d / NPH, half = PR / 2;
-        const int p = (int)(mp / half);
-        const long long fp = mp % half;
-        const long long f0 = (fp / s) * 2 * s + fp % s;
-        xm = x_at(x, p, f0, -s, c, PR, BT, T);
-        x0 = x_at(x, p, f0, 0, c, PR, BT, T);
-        x1 = x_at(x, p, f0, s, c, PR, BT, T);
-        x2 = x_at(x, p, f0, 2 * s, c, PR, BT, T);
-    }
+    const int pp = (int)(mp / PR);
+    const long long f = mp % PR;
+    int p0, p1;
+    pair_phases(pp, d, p0, p1);
+    const f32x4 xm = x_at(x, p0 - d, f, 0, c, PR, BT, T), x0 = x_at(x, p0, f, 0, c, PR, BT, T),
+                x1 = x_at(x, p1, f, 0, c, PR, BT, T), x2 = x_at(x, p1 + d, f, 0, c, PR, BT, T);
     const long long o = mp * C + c, plane = Mh * C;
     *reinterpret_cast<f32x4*>(U + o) = xm - x1;
     *reinterpret_cast<f32x4*>(U + plane + o) = x0 + x1;
@@ -100,26 +93,21 @@ __global__ void wino_weights_kernel(const float* __restrict__ in_Bt, float* __re
     G[3 * plane + idx] = (float)(-wp);
 }
 
-// V[npp][4][1024][160] from cond_Bt [32][1024][320]
+// V[16][4][1024][160] from cond_Bt [32][1024][320]: (first half of V_p0, (V_p0 + V_p1) / 2, (V_p0 - V_p1) / 2 second halves,
+// first half of V_p1)
 __global__ void wino_cond_weights_kernel(const float* __restrict__ cond_Bt, float* __restrict__ V, int d) {
-    const int npp = d < NPH ? NPH / 2 : NPH;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)npp * 2 * C * KH) return;
+    if (idx >= (long long)(NPH / 2) * 2 * C * KH) return;
     const int k = (int)(idx % KH), n = (int)((idx / KH) % (2 * C)), pp = (int)(idx / ((long long)KH * 2 * C));
-    int p0 = pp, p1 = pp;
-    if (d < NPH) pair_phases(pp, d, p0, p1);
+    int p0, p1;
+    pair_phases(pp, d, p0, p1);
     const float* r0 = cond_Bt + ((long long)p0 * 2 * C + n) * KMEL;
     const float* r1 = cond_Bt + ((long long)p1 * 2 * C + n) * KMEL;
     const long long zs = (long long)2 * C * KH, o = (long long)pp * 4 * zs + (long long)n * KH + k;
     V[o] = r0[k];                                                              // first half of c0 -> m0
+    V[o + zs] = (float)(((double)r0[KH + k] + (double)r1[KH + k]) * 0.5);      // s
+    V[o + 2 * zs] = (float)(((double)r0[KH + k] - (double)r1[KH + k]) * 0.5);  // e
     V[o + 3 * zs] = r1[k];                                                     // first half of c1 -> -m3
-    if (d < NPH) {
-        V[o + zs] = (float)(((double)r0[KH + k] + (double)r1[KH + k]) * 0.5);  // s: weights averaged
-        V[o + 2 * zs] = (float)(((double)r0[KH + k] - (double)r1[KH + k]) * 0.5);
-    } else {
-        V[o + zs] = r0[KH + k];                                                // s / e are formed on the mel side
-        V[o + 2 * zs] = r0[KH + k];
-    }
 }
 
 // bias planes [4][1024] = (b, 0, 0, b)
@@ -139,28 +127,18 @@ __device__ __forceinline__ float melwin(const float* __restrict__ mel, long long
     return (int)(f % T) - q >= 0 ? mel[(f - q) * 80 + j] : 0.f;
 }
 
-// melP[4][rows][160]: the conditioning operands of the four products.  s = 0: dilations < 32 (rows = frames, planes
-// (lo, hi, hi, lo) halves of the window); s > 0: frame pairs (f0, f0 + s): (lo(f0), (hi(f0) + hi(f1)) / 2, (hi(f0) - hi(f1)) / 2, lo(f1))
-__global__ void wino_mel_planes_kernel(const float* __restrict__ mel, float* __restrict__ P, int s, int rows, int BT, int T) {
+// F(2,3) mel planes [4][rows][160]: (lo, hi, hi, lo) halves of the mel window of a frame
+__global__ void wino_mel_planes_kernel(const float* __restrict__ mel, float* __restrict__ P, int rows, int BT, int T) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)rows * KH) return;
     const long long r = idx / KH;
     const int k = (int)(idx % KH);
     const long long plane = (long long)rows * KH;
-    if (s == 0) {
-        const float lo = melwin(mel, r, k, BT, T), hi = melwin(mel, r, KH + k, BT, T);
-        P[idx] = lo;
-        P[plane + idx] = hi;
-        P[2 * plane + idx] = hi;
-        P[3 * plane + idx] = lo;
-    } else {
-        const long long f0 = (r / s) * 2 * s + r % s, f1 = f0 + s;
-        const float h0 = melwin(mel, f0, KH + k, BT, T), h1 = melwin(mel, f1, KH + k, BT, T);
-        P[idx] = melwin(mel, f0, k, BT, T);
-        P[plane + idx] = 0.5f * (h0 + h1);
-        P[2 * plane + idx] = 0.5f * (h0 - h1);
-        P[3 * plane + idx] = melwin(mel, f1, k, BT, T);
-    }
+    const float lo = melwin(mel, r, k, BT, T), hi = melwin(mel, r, KH + k, BT, T);
+    P[idx] = lo;
+    P[plane + idx] = hi;
+    P[2 * plane + idx] = hi;
+    P[3 * plane + idx] = lo;
 }
 
 // y0 = P0 + P1 + P2, y1 = P3 + P1 - P2; acts = tanh * sigmoid (column groups of 64: 32 tanh, then their 32 sigmoid partners)
@@ -185,24 +163,12 @@ __global__ void wino_combine_kernel(const float* __restrict__ P, float* __restri
         g0[k] = gate_tanh_sigmoid(t0[k], s0[k]);
         g1[k] = gate_tanh_sigmoid(t1[k], s1[k]);
     }
-    long long r0, r1;
-    if (d < NPH) {
-        const int pp = (int)(mp / PR);
-        const long long f = mp % PR;
-        int p0, p1;
-        pair_phases(pp, d, p0, p1);
-        r0 = (long long)p0 * PR + f;
-        r1 = (long long)p1 * PR + f;
-    } else {
-        const int s = d / NPH, half = PR / 2;
-        const int p = (int)(mp / half);
-        const long long fp = mp % half;
-        const long long f0 = (fp / s) * 2 * s + fp % s;
-        r0 = (long long)p * PR + f0;
-        r1 = r0 + s;
-    }
-    *reinterpret_cast<f32x4*>(acts + r0 * C + ch) = g0;
-    *reinterpret_cast<f32x4*>(acts + r1 * C + ch) = g1;
+    const int pp = (int)(mp / PR);
+    const long long f = mp % PR;
+    int p0, p1;
+    pair_phases(pp, d, p0, p1);
+    *reinterpret_cast<f32x4*>(acts + ((long long)p0 * PR + f) * C + ch) = g0;
+    *reinterpret_cast<f32x4*>(acts + ((long long)p1 * PR + f) * C + ch) = g1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -492,7 +458,7 @@ int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, i
     const MelPlanes mp(PR);
     HIPCHK(e, wg.wino_mel.ensure(mp.total * 4));
     float* base = wg.wino_mel.f();
-    hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base + mp.f23, 0, PR, BT, T);
+    hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base + mp.f23, PR, BT, T);
     hipLaunchKernelGGL(wino4_mel_planes_kernel, dim3(blocks_for((long long)PR * K4)), dim3(256), 0, st, d_mel, base + mp.f43p, PR, BT, T);
     for (int si = 0; si < 3; ++si)
         hipLaunchKernelGGL(wino4_mel_planes_frames_kernel, dim3(blocks_for((long long)6 * PRq * K4)), dim3(256), 0, st, d_mel,

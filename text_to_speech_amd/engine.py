@@ -421,9 +421,9 @@ class HipEngine:
         return {2: 'fused', 1: 'persistent', 0: 'graph'}.get(self._lib.tts_hip_last_decoder_mode(self._h), 'none')
 
     def set_waveglow_form(self, form: str) -> None:
-        """How the exact-fp32 vocoder evaluates the dilated convolutions of WN layers 1 - 7: 'winograd' (default: F(2,3) along
-        the tap axis whenever the call shape allows it -- 256-row tiles and utterance lengths that are a multiple of 8 frames)
-        or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
+        """How the fp32 vocoder evaluates the dilated convolutions of WN layers 1 - 7: 'winograd' (default: minimal filtering
+        along the tap axis -- F(4,3), F(2,3) for dilation 16 -- whenever the call shape allows it: 256-row tiles and utterance
+        lengths that are a multiple of 16 frames) or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
         forms = {'direct': 0, 'winograd': 1}
         if form not in forms:
             raise ValueError(f'form must be one of {tuple(forms)}, got {form!r}')
