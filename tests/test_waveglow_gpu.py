@@ -153,8 +153,8 @@ def test_waveglow_256_row_tiles_match_oracle(gpu_engine, wg_weights, wg_cfg):
 
 def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_weights, wg_cfg):
     """The fp32 path evaluates WN layers 1 - 7 in their Winograd form (F(4,3); F(2,3) for dilation 16) when the call takes the
-    256-row tiles and the utterance length is a multiple of 16 frames (csrc/wn_wino.hip): both forms against the oracle on the
-    same inputs, the switch, the report of which one ran, and the fall-back for a length that is not a multiple of 16."""
+    256-row tiles (csrc/wn_wino.hip): both forms against the oracle on the same inputs, the switch, the report of which one ran,
+    utterance lengths that leave partial frame groups, and the small shapes that keep the direct form."""
     from oracle import waveglow_ref
     mel, z = _inputs(2, 128, seed=33)
     ref = waveglow_ref.infer(mel, wg_weights, wg_cfg, z=z, sigma=1.0)
@@ -169,14 +169,15 @@ def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_we
     e_w, e_d, diff = rms(wino - ref), rms(direct - ref), rms(wino - direct)
     print(f'winograd rms_err={e_w:.3e}  direct rms_err={e_d:.3e}  winograd vs direct {diff:.3e}')
     assert e_w <= RMS_TOL and e_d <= RMS_TOL and diff <= 5e-6
-    # 2 x 126 frames: the same 256-row tiles, but groups of frames would straddle the utterances -> direct form
-    mel2, z2 = _inputs(2, 126, seed=34)
-    out2 = gpu_engine.waveglow_infer(mel2, z=z2, sigma=1.0)
-    assert gpu_engine.last_waveglow_form == 'direct'
-    assert rms(out2 - waveglow_ref.infer(mel2, wg_weights, wg_cfg, z=z2, sigma=1.0)) <= RMS_TOL
-    mel4, z4 = _inputs(2, 120, seed=36)                             # a multiple of 8 but not of 16 frames -> direct as well
-    gpu_engine.waveglow_infer(mel4, z=z4, sigma=1.0)
-    assert gpu_engine.last_waveglow_form == 'direct'
+    # utterance lengths that are not a multiple of the group sizes (2 x 126 and 2 x 121 frames, same 256-row tiles): the frame
+    # groups are cut per utterance (the last group of an utterance is partial), so these run the Winograd form as well
+    for T2, seed in ((126, 34), (121, 36)):
+        mel2, z2 = _inputs(2, T2, seed=seed)
+        out2 = gpu_engine.waveglow_infer(mel2, z=z2, sigma=1.0)
+        assert gpu_engine.last_waveglow_form == 'winograd'
+        e2 = rms(out2 - waveglow_ref.infer(mel2, wg_weights, wg_cfg, z=z2, sigma=1.0))
+        print(f'2 x {T2} frames: winograd rms_err={e2:.3e}')
+        assert e2 <= RMS_TOL
     # small calls (64- / 128-row tiles) always take the direct form; the fp16 modes have no Winograd form
     m3, z3 = _inputs(1, 16, seed=35)
     gpu_engine.waveglow_infer(m3, z=z3)

@@ -757,7 +757,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     }
     hipStream_t st = e->stream;
     // exact-fp32 path, 256-row tiles: layers 1 .. 7 of a flow run in their Winograd form (wn_wino.hip)
-    bool wino = precision == 0 && !row64 && !tile128 && !tile64 && T % 16 == 0 && wg.form_mode == 1;
+    bool wino = precision == 0 && !row64 && !tile128 && !tile64 && wg.form_mode == 1;
     if (wino) {
         // its operands (6.4 GB of weight planes on first use, 2.6 GB of workspace at config 2) are extra: when the device
         // cannot hold them this handle keeps the direct form from now on instead of failing the call

@@ -189,6 +189,24 @@ constexpr int K4 = 224, SA = 112, SB = 96, SC = 112;       // conditioning K of 
 
 __device__ __forceinline__ int group_phase0(int gp, int d) { return (gp / d) * 4 * d + gp % d; }
 
+// Frame groups (dilations >= 32, s = d / 32): every utterance owns G = 4 ceil(T / 16) group rows per phase for every s, so
+// that no group straddles two utterances whatever T is; group g of an utterance starts at frame t0 = (g / s) 4s + g % s and
+// covers t0 + j s (frames >= T: inputs read as zero, outputs are not written; t0 >= T: an empty group).
+__host__ __device__ __forceinline__ int frame_groups_per_utt(int T) { return (T + 15) / 16 * 4; }
+__device__ __forceinline__ bool frame_group(long long gf, int s, int BT, int T, int& b, int& t0) {
+    const int G = frame_groups_per_utt(T);
+    b = (int)(gf / G);
+    const int g = (int)(gf % G);
+    t0 = (g / s) * 4 * s + g % s;
+    return (long long)b * T < BT && t0 < T;
+}
+// x row of (phase p, utterance b, frame t), zero outside the utterance
+__device__ __forceinline__ f32x4 x_bt(const float* __restrict__ x, int p, int b, int t, int c, int PR, int T) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (t < 0 || t >= T) return zero;
+    return *reinterpret_cast<const f32x4*>(x + ((long long)p * PR + (long long)b * T + t) * C + c);
+}
+
 __global__ void wino4_prepass_kernel(const float* __restrict__ x, float* __restrict__ U, int d, int PR, int BT, int T, long long Mq) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Mq * (C / 4)) return;
@@ -204,10 +222,11 @@ __global__ void wino4_prepass_kernel(const float* __restrict__ x, float* __restr
     } else {                                               // four frames f0 + j s of one phase (PRq group rows per phase)
         const int s = d / NPH, PRq = (int)(Mq / NPH);
         const int p = (int)(mg / PRq);
-        const long long gf = mg % PRq;
-        const long long f0 = (gf / s) * 4 * s + gf % s;
+        int b, t0;
+        const bool ok = frame_group(mg % PRq, s, BT, T, b, t0);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = x_at(x, p, f0, (i - 1) * s, c, PR, BT, T);
+        for (int i = 0; i < 6; ++i) v[i] = ok ? x_bt(x, p, b, t0 + (i - 1) * s, c, PR, T) : zero;
     }
     const long long o = mg * C + c, plane = Mq * C;
     *reinterpret_cast<f32x4*>(U + o) = 4.f * v[0] - 5.f * v[2] + v[4];
@@ -320,27 +339,28 @@ __global__ void wino4_cond_weights_frames_kernel(const float* __restrict__ cond_
     V[idx] = col >= 0 ? cond_Bt[((long long)p * 2 * C + n) * KMEL + col] : 0.f;
 }
 
-// mel planes [6][rows][224] for s = d / 32: row gf <-> frames f_j = (gf / s) 4 s + gf % s + j s; product k, slice column:
-// sum_j coef[k][j] melwin(f_j)
+// mel planes [6][rows][224] for s = d / 32: group row gf <-> frames t0 + j s of its utterance (frame_group); product k, slice
+// column: sum_j coef[k][j] melwin(f_j) over the frames inside the utterance
 __global__ void wino4_mel_planes_frames_kernel(const float* __restrict__ mel, float* __restrict__ P, int s, int rows, int BT, int T) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)6 * rows * K4) return;
     const int kk = (int)(idx % K4), k = (int)(idx / ((long long)rows * K4));
-    const long long gf = (idx / K4) % rows;
-    const long long f0 = (gf / s) * 4 * s + gf % s;
+    int b, t0;
+    const bool ok = frame_group((idx / K4) % rows, s, BT, T, b, t0);
     int row, which;
     const int col = slice_col(k, kk, row, which);
     double acc = 0.0;
-    if (col >= 0) {
+    if (ok && col >= 0) {
         const double (*cf)[4] = which == 0 ? W4_A : which == 1 ? W4_B : W4_C;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc += cf[row][j] * (double)melwin(mel, f0 + j * s, col, BT, T);
+        for (int j = 0; j < 4; ++j)
+            if (t0 + j * s < T) acc += cf[row][j] * (double)melwin(mel, (long long)b * T + t0 + j * s, col, BT, T);
     }
     P[idx] = (float)acc;
 }
 
 __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ acts, int d,
-                                     int PR, long long Mq) {
+                                     int PR, int BT, int T, long long Mq) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Mq * (C / 4)) return;
     const long long mg = idx / (C / 4);
@@ -364,6 +384,7 @@ __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* _
     s[2] = b[1] + b[2] + 4.f * (b[3] + b[4]) + bb;
     s[3] = b[1] - b[2] + 8.f * (b[3] - b[4]) + b[5] + bb;
     long long r0, rstep;                                   // acts row of output 0 and the row step between outputs
+    int nout = 4;                                          // outputs of this group that exist
     if (d < NPH) {
         const int gp = (int)(mg / PR);
         r0 = (long long)group_phase0(gp, d) * PR + mg % PR;
@@ -371,14 +392,16 @@ __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* _
     } else {
         const int sf = d / NPH, PRq = (int)(Mq / NPH);
         const int p = (int)(mg / PRq);
-        const long long gf = mg % PRq;
-        const long long f0 = (gf / sf) * 4 * sf + gf % sf;
-        if (f0 + 3 * sf >= PR) return;                     // padding group rows past the phase block
-        r0 = (long long)p * PR + f0;
+        int b, t0;
+        if (!frame_group(mg % PRq, sf, BT, T, b, t0)) return;                     // padding / empty group
+        r0 = (long long)p * PR + (long long)b * T + t0;
         rstep = sf;
+        nout = (T - t0 + sf - 1) / sf;                     // frames t0 + j sf < T
+        nout = nout > 4 ? 4 : nout;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if (j >= nout) break;
         f32x4 g;
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = gate_tanh_sigmoid(t[j][k], s[j][k]);
@@ -390,8 +413,8 @@ inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 // Per-layer operands (once, on the first call that takes this path): G, V and the bias planes of layers 1 .. 7 of every flow
-// group rows per phase block of the frame-group layers (dilations >= 32): PR / 4, padded to the 128-row tile
-static inline int frame_group_rows(int PR) { return (PR / 4 + 127) / 128 * 128; }
+// group rows per phase block of the frame-group layers (dilations >= 32): B x 4 ceil(T / 16), padded to the 128-row tile
+static inline int frame_group_rows(int BT, int T) { return ((BT / T) * frame_groups_per_utt(T) + 127) / 128 * 128; }
 
 int waveglow_build_wino(tts_hip_engine* e) {
     WaveGlowDev& wg = e->wg;
@@ -434,8 +457,8 @@ int waveglow_build_wino(tts_hip_engine* e) {
 // Layout of the per-call mel planes (floats): [F(2,3): 4][PR][160] | [F(4,3) phases: 6][PR][224] | 3 x [F(4,3) frames: 6][PRq][224]
 struct MelPlanes {
     size_t f23, f43p, f43f[3], total;
-    MelPlanes(int PR) {
-        const size_t PRq = (size_t)frame_group_rows(PR);
+    MelPlanes(int PR, int BT, int T) {
+        const size_t PRq = (size_t)frame_group_rows(BT, T);
         f23 = 0;
         f43p = (size_t)4 * PR * KH;
         f43f[0] = f43p + (size_t)6 * PR * K4;
@@ -450,12 +473,12 @@ int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, i
     WaveGlowDev& wg = e->wg;
     hipStream_t st = e->stream;
     const long long Mh = (long long)(NPH / 2) * PR;
-    const int PRq = frame_group_rows(PR);
+    const int PRq = frame_group_rows(BT, T);
     // U / P planes: F(2,3) 4 x (16 PR) rows, F(4,3) phases 6 x (8 PR), F(4,3) frames 6 x (32 PRq)
     const size_t rows = (size_t)std::max<long long>(4 * Mh, (long long)6 * NPH * PRq);
     HIPCHK(e, wg.wino_U.ensure(rows * C * 4));
     HIPCHK(e, wg.wino_P.ensure(rows * 2 * C * 4));
-    const MelPlanes mp(PR);
+    const MelPlanes mp(PR, BT, T);
     HIPCHK(e, wg.wino_mel.ensure(mp.total * 4));
     float* base = wg.wino_mel.f();
     hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base + mp.f23, PR, BT, T);
@@ -474,7 +497,7 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     const int d = 1 << i;
     float* U = wg.wino_U.f();
     float* P = wg.wino_P.f();
-    const MelPlanes mp(PR);
+    const MelPlanes mp(PR, BT, T);
     GemmArgs g{};
     g.N = 2 * C;
     g.nseg = 2;
@@ -490,13 +513,13 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     g.wide_epi = 1;
     if (d != 16) {                                         // F(4,3): groups of four phases (d <= 8) or of four frames (d >= 32)
         const bool phases = d < NPH;
-        const int PRq = frame_group_rows(PR);
+        const int PRq = frame_group_rows(BT, T);
         const long long Mq = phases ? (long long)(NPH / 4) * PR : (long long)NPH * PRq;
         hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
         g.M = (int)Mq;
         g.nphase = phases ? NPH / 4 : NPH;
         g.phase_rows = phases ? PR : PRq;
-        g.frames = phases ? BT : BT / 4;
+        g.frames = phases ? BT : (BT / T) * frame_groups_per_utt(T);
         g.L = g.phase_rows;
         const float* mel6 = wg.wino_mel.f() + (phases ? mp.f43p : mp.f43f[i - 5]);
         g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mq, 1};
@@ -508,7 +531,7 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
         timing_begin(e, 0);
         HIPCHK(e, phases ? gemm_wn_wino(g, 6, st) : gemm_wn_wino_128(g, 6, st));
         timing_end(e);
-        hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, Mq);
+        hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, BT, T, Mq);
         HIPCHK(e, hipGetLastError());
         return TTS_HIP_OK;
     }
