@@ -731,12 +731,20 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     const int BT = B * T;                                        // frames
     // rows per phase block, padded to the M tile: 256-row tiles unless 128-row tiles save at least 5 % of the rows
     const int pr256 = (BT + 255) / 256 * 256, pr128 = (BT + 127) / 128 * 128, pr64 = (BT + 63) / 64 * 64;
-    const bool tile128 = pr128 * 1.05 < pr256;
+    bool tile128 = pr128 * 1.05 < pr256;
     // short utterances (a sentence at batch 1): 64-row tiles when they save padding
     const int pr_big = tile128 ? pr128 : pr256;
-    const bool row64 = x3 ? pr64 * 1.25 < pr256      // split fp16 has two tile shapes: 64 x 128 (about 25 % more time per row) and 256 x 256
-                          : BT <= 512 &&
-                            (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
+    bool row64 = x3 ? pr64 * 1.25 < pr256      // split fp16 has two tile shapes: 64 x 128 (about 25 % more time per row) and 256 x 256
+                    : BT <= 512 &&
+                      (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
+    // fp32: the Winograd form (wn_wino.hip) only exists on the 256-row tiles and executes K ~1 160 per output instead of
+    // 1 856, so a call whose rows would pad better on smaller tiles still takes the 256-row tiles when that is clearly less
+    // work (its two HBM-bound passes and the shorter tiles priced at +35 %: one sentence of 800 frames 85.1 -> 71.9 ms, 513
+    // or 600 frames break even and keep the smaller tiles)
+    if (precision == 0 && wg.form_mode == 1 && (tile128 || row64)) {
+        const double direct = (double)(row64 ? pr64 : pr128) * 1856.0, wino256 = (double)pr256 * 1160.0 * 1.35;
+        if (wino256 < direct) tile128 = row64 = false;
+    }
     const int PR = row64 ? pr64 : (tile128 && !x3) ? pr128 : pr256;
     const int NP = x3 ? 2 : 1;                                   // fp16 planes per operand
     const long long M = (long long)NPH * PR;                     // phase-major rows (incl. padding)
