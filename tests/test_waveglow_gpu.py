@@ -187,16 +187,24 @@ def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_we
 
 
 def test_waveglow_config2_rows_equal_batch1_runs(gpu_engine):
-    """Full BASELINE.json config 2 (8 x 800 frames, 256-row tiles) against batch-1 runs of single rows (128-row tiles):
-    a size-independent property (utterances are independent) that also cross-checks the two tile configurations."""
+    """Full BASELINE.json config 2 (8 x 800 frames, 256-row tiles, Winograd form) against batch-1 runs of single rows in both
+    forms (Winograd on 256-row tiles, direct on 128-row tiles): a size-independent property (utterances are independent) that
+    also cross-checks the two forms and tile configurations at the full size."""
     mel, z = _inputs(8, 800, seed=41)
     full = gpu_engine.waveglow_infer(mel, z=z)
     assert full.shape == (8, 800 * 256) and np.isfinite(full).all()
     full16 = gpu_engine.waveglow_infer(mel, z=z, precision='f16')
     assert np.isfinite(full16).all() and rms(full16 - full) <= F16_RMS_TOL
+    assert gpu_engine.last_waveglow_form == 'direct'              # (the fp16 modes have no Winograd form)
     for b in (0, 5):
-        single = gpu_engine.waveglow_infer(mel[b:b + 1], z=z[b:b + 1])
-        assert rms(single[0] - full[b]) <= 5e-6
+        single = gpu_engine.waveglow_infer(mel[b:b + 1], z=z[b:b + 1])         # Winograd form on 256-row tiles, like `full`
+        assert gpu_engine.last_waveglow_form == 'winograd' and rms(single[0] - full[b]) <= 5e-6
+        try:                                                                   # ... and the direct form on 128-row tiles
+            gpu_engine.set_waveglow_form('direct')
+            direct = gpu_engine.waveglow_infer(mel[b:b + 1], z=z[b:b + 1])
+        finally:
+            gpu_engine.set_waveglow_form('winograd')
+        assert rms(direct[0] - full[b]) <= 5e-6
         single16 = gpu_engine.waveglow_infer(mel[b:b + 1], z=z[b:b + 1], precision='f16')
         assert rms(single16[0] - full16[b]) <= 5e-5      # fp16 rounding of differently-ordered fp32 sums
 
