@@ -25,8 +25,7 @@
 // combinations built at load.  d >= 32 (s = d / 32 frames): four FRAMES f0 + j s of one phase, f0 = (gf / s) 4s + gf % s; the
 // outputs share the weights and the combinations are MEL combinations built once per call (group rows per phase padded to
 // the 128-row tile).  d = 16: four outputs would be two phases x two frames and share neither, so that layer runs F(2,3) on
-// the 16 phase pairs (p0, p0 + 16).  Utterance lengths must be a multiple of 16 frames (no group straddles an utterance),
-// else the direct kernel runs.
+// the 16 phase pairs (p0, p0 + 16).  Frame groups are cut per utterance (frame_group below), so any utterance length works.
 //
 // Numerics: every operand stays fp32, weight / mel combinations are formed in fp64 and rounded once.  F(4,3)'s transform
 // constants (4, 5, 8, 1/6, 1/24) cost accuracy: error of one layer ~3x the direct form's (F(2,3): 1.3x); end to end against
