@@ -53,9 +53,8 @@ struct WgLayerDev {
     _Float16* in_Bt_x3 = nullptr;   // split-fp16 mode: the same three matrices as [2 planes][...] (hi, lo), built on first use
     _Float16* cond_Bt_x3 = nullptr;
     _Float16* rs_Bt_x3 = nullptr;
-    float* wino_G = nullptr;    // Winograd form (wn_wino.hip; built on first use): [4][1024][512] tap combinations,
-    float* wino_V = nullptr;    //   [16 or 32][4][1024][160] conditioning halves, [4][1024] bias planes
-    float* wino_bias = nullptr;
+    float* wino_G = nullptr;    // Winograd form (wn_wino.hip; built on first use): [6][1024][512] tap combinations and the
+    float* wino_V = nullptr;    //   conditioning planes of the layer's group kind ([8 or 32][6][1024][224] / [16][4][1024][320])
     float* rs_Bt = nullptr;     // [512][512] residual half of res_skip (layers 0..6)
     float* rs_bias = nullptr;   // [512]
     int rs_n = 0;

@@ -40,14 +40,8 @@ using namespace ttsgemm;
 namespace {
 constexpr int C = 512;
 constexpr int NPH = 32;
-constexpr int KMEL = 320, KH = 160;
+constexpr int KMEL = 320;
 constexpr int KCONV = 3 * C;
-
-// (p0, p1) of pair phase pp for dilation d < 32
-__device__ __forceinline__ void pair_phases(int pp, int d, int& p0, int& p1) {
-    p0 = (pp / d) * 2 * d + pp % d;
-    p1 = p0 + d;
-}
 
 // x row of (phase ps -- may leave [0, 32): carried into the neighbouring frame -- , frame row f + df), zero outside the utterance
 __device__ __forceinline__ f32x4 x_at(const float* __restrict__ x, int ps, long long f, int df, int c, int PR, int BT, int T) {
@@ -59,115 +53,11 @@ __device__ __forceinline__ f32x4 x_at(const float* __restrict__ x, int ps, long 
     return *reinterpret_cast<const f32x4*>(x + ((long long)(ps & 31) * PR + f + carry) * C + c);
 }
 
-// F(2,3), pairs of phases (p0, p1 = p0 + d): U planes.  One thread per (pair row, 4 channels).
-__global__ void wino_prepass_kernel(const float* __restrict__ x, float* __restrict__ U, int d, int PR, int BT, int T, long long Mh) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Mh * (C / 4)) return;
-    const long long mp = idx / (C / 4);
-    const int c = (int)(idx % (C / 4)) * 4;
-    const int pp = (int)(mp / PR);
-    const long long f = mp % PR;
-    int p0, p1;
-    pair_phases(pp, d, p0, p1);
-    const f32x4 xm = x_at(x, p0 - d, f, 0, c, PR, BT, T), x0 = x_at(x, p0, f, 0, c, PR, BT, T),
-                x1 = x_at(x, p1, f, 0, c, PR, BT, T), x2 = x_at(x, p1 + d, f, 0, c, PR, BT, T);
-    const long long o = mp * C + c, plane = Mh * C;
-    *reinterpret_cast<f32x4*>(U + o) = xm - x1;
-    *reinterpret_cast<f32x4*>(U + plane + o) = x0 + x1;
-    *reinterpret_cast<f32x4*>(U + 2 * plane + o) = x1 - x0;
-    *reinterpret_cast<f32x4*>(U + 3 * plane + o) = x0 - x2;
-}
-
-// G[4][1024][512] from in_Bt [1024][1536] (K tap-interleaved in chunks of 16): (W-, (W- + W0 + W+) / 2, (W- - W0 + W+) / 2, -W+)
-__global__ void wino_weights_kernel(const float* __restrict__ in_Bt, float* __restrict__ G) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * C * C) return;
-    const int n = idx / C, c = idx % C;
-    const float* row = in_Bt + (long long)n * KCONV + (c / 16) * 48 + c % 16;
-    const double wm = row[0], w0 = row[16], wp = row[32];
-    const long long plane = (long long)2 * C * C;
-    G[idx] = (float)wm;
-    G[plane + idx] = (float)((wm + w0 + wp) * 0.5);
-    G[2 * plane + idx] = (float)((wm - w0 + wp) * 0.5);
-    G[3 * plane + idx] = (float)(-wp);
-}
-
-// V[16][4][1024][160] from cond_Bt [32][1024][320]: (first half of V_p0, (V_p0 + V_p1) / 2, (V_p0 - V_p1) / 2 second halves,
-// first half of V_p1)
-__global__ void wino_cond_weights_kernel(const float* __restrict__ cond_Bt, float* __restrict__ V, int d) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)(NPH / 2) * 2 * C * KH) return;
-    const int k = (int)(idx % KH), n = (int)((idx / KH) % (2 * C)), pp = (int)(idx / ((long long)KH * 2 * C));
-    int p0, p1;
-    pair_phases(pp, d, p0, p1);
-    const float* r0 = cond_Bt + ((long long)p0 * 2 * C + n) * KMEL;
-    const float* r1 = cond_Bt + ((long long)p1 * 2 * C + n) * KMEL;
-    const long long zs = (long long)2 * C * KH, o = (long long)pp * 4 * zs + (long long)n * KH + k;
-    V[o] = r0[k];                                                              // first half of c0 -> m0
-    V[o + zs] = (float)(((double)r0[KH + k] + (double)r1[KH + k]) * 0.5);      // s
-    V[o + 2 * zs] = (float)(((double)r0[KH + k] - (double)r1[KH + k]) * 0.5);  // e
-    V[o + 3 * zs] = r1[k];                                                     // first half of c1 -> -m3
-}
-
-// bias planes [4][1024] = (b, 0, 0, b)
-__global__ void wino_bias_kernel(const float* __restrict__ b, float* __restrict__ b4) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= 2 * C) return;
-    b4[n] = b[n];
-    b4[2 * C + n] = 0.f;
-    b4[4 * C + n] = 0.f;
-    b4[6 * C + n] = b[n];
-}
-
 // mel window of frame f: [mel_t | mel_{t-1} | mel_{t-2} | mel_{t-3}][80], zeros before the start of the utterance; column k
 __device__ __forceinline__ float melwin(const float* __restrict__ mel, long long f, int k, int BT, int T) {
     if (f >= BT) return 0.f;
     const int q = k / 80, j = k % 80;
     return (int)(f % T) - q >= 0 ? mel[(f - q) * 80 + j] : 0.f;
-}
-
-// F(2,3) mel planes [4][rows][160]: (lo, hi, hi, lo) halves of the mel window of a frame
-__global__ void wino_mel_planes_kernel(const float* __restrict__ mel, float* __restrict__ P, int rows, int BT, int T) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)rows * KH) return;
-    const long long r = idx / KH;
-    const int k = (int)(idx % KH);
-    const long long plane = (long long)rows * KH;
-    const float lo = melwin(mel, r, k, BT, T), hi = melwin(mel, r, KH + k, BT, T);
-    P[idx] = lo;
-    P[plane + idx] = hi;
-    P[2 * plane + idx] = hi;
-    P[3 * plane + idx] = lo;
-}
-
-// y0 = P0 + P1 + P2, y1 = P3 + P1 - P2; acts = tanh * sigmoid (column groups of 64: 32 tanh, then their 32 sigmoid partners)
-__global__ void wino_combine_kernel(const float* __restrict__ P, float* __restrict__ acts, int d, int PR, long long Mh) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Mh * (C / 4)) return;
-    const long long mp = idx / (C / 4);
-    const int ch = (int)(idx % (C / 4)) * 4;
-    const int col = (ch >> 5) * 64 + (ch & 31);
-    const long long plane = Mh * 2 * C, o = mp * 2 * C + col;
-    f32x4 a[4], b[4];
-#pragma unroll
-    for (int z = 0; z < 4; ++z) {
-        a[z] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + z * plane + o));       // read once (371 -> 329 us)
-        b[z] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + z * plane + o + 32));
-    }
-    const f32x4 t0 = a[0] + a[1] + a[2], s0 = b[0] + b[1] + b[2];
-    const f32x4 t1 = a[3] + a[1] - a[2], s1 = b[3] + b[1] - b[2];
-    f32x4 g0, g1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        g0[k] = gate_tanh_sigmoid(t0[k], s0[k]);
-        g1[k] = gate_tanh_sigmoid(t1[k], s1[k]);
-    }
-    const int pp = (int)(mp / PR);
-    const long long f = mp % PR;
-    int p0, p1;
-    pair_phases(pp, d, p0, p1);
-    *reinterpret_cast<f32x4*>(acts + ((long long)p0 * PR + f) * C + ch) = g0;
-    *reinterpret_cast<f32x4*>(acts + ((long long)p1 * PR + f) * C + ch) = g1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -199,6 +89,15 @@ __device__ __forceinline__ bool frame_group(long long gf, int s, int BT, int T, 
     t0 = (g / s) * 4 * s + g % s;
     return (long long)b * T < BT && t0 < T;
 }
+// Dilation 16: the four outputs l + 16 j of a group are two phases x two frames -- (p0, t), (p0 + 16, t), (p0, t + 1),
+// (p0 + 16, t + 1) for p0 < 16 and even t; every utterance owns ceil(T / 2) group rows per p0.
+__host__ __device__ __forceinline__ int mixed_groups_per_utt(int T) { return (T + 1) / 2; }
+__device__ __forceinline__ bool mixed_group(long long gm, int BT, int T, int& b, int& t0) {
+    const int G = mixed_groups_per_utt(T);
+    b = (int)(gm / G);
+    t0 = 2 * (int)(gm % G);
+    return (long long)b * T < BT;                          // (t0 < T always)
+}
 // x row of (phase p, utterance b, frame t), zero outside the utterance
 __device__ __forceinline__ f32x4 x_bt(const float* __restrict__ x, int p, int b, int t, int c, int PR, int T) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -212,7 +111,18 @@ __global__ void wino4_prepass_kernel(const float* __restrict__ x, float* __restr
     const long long mg = idx / (C / 4);
     const int c = (int)(idx % (C / 4)) * 4;
     f32x4 v[6];
-    if (d < NPH) {                                         // four phases of one frame
+    if (d == 16) {                                         // two phases x two frames (PRm group rows per p0)
+        const int PRm = (int)(Mq / 16);
+        const int p0 = (int)(mg / PRm);
+        int b, t0;
+        const bool ok = mixed_group(mg % PRm, BT, T, b, t0);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int ps = p0 + 16 * (i - 1);
+            v[i] = ok ? x_bt(x, ps & 31, b, t0 + (ps >> 5), c, PR, T) : zero;
+        }
+    } else if (d < NPH) {                                  // four phases of one frame
         const int gp = (int)(mg / PR);
         const long long f = mg % PR;
         const int p0 = group_phase0(gp, d);
@@ -358,6 +268,39 @@ __global__ void wino4_mel_planes_frames_kernel(const float* __restrict__ mel, fl
     P[idx] = (float)acc;
 }
 
+// Dilation 16.  With c_j = mel(t_j) V(p_j), product k of the subset {1, 2, 3, 4} needs sum_j coef[k][j] c_j, and every row of
+// that subset's coefficient matrix is an outer product (over {t, t + 1}) x (over {p0, p0 + 16}) -- (2/3, -1/6) x (1, +-1) for
+// products 1, 2 and (-1, 1) x (1/6, +-1/12) for products 3, 4 -- so each is ONE K = 320 product of a mel combination and a
+// weight combination.  Products 0 and 5 carry no conditioning (their launch runs K = 512).
+// Vm[16][4][1024][320] (products 1 .. 4): V(p0) + V(p1), V(p0) - V(p1), V(p0) / 6 + V(p1) / 12, V(p0) / 6 - V(p1) / 12
+__global__ void wino4_cond_weights_mixed_kernel(const float* __restrict__ cond_Bt, float* __restrict__ V) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)16 * 2 * C * KMEL) return;
+    const int k = (int)(idx % KMEL), n = (int)((idx / KMEL) % (2 * C)), p0 = (int)(idx / ((long long)KMEL * 2 * C));
+    const double v0 = cond_Bt[((long long)p0 * 2 * C + n) * KMEL + k], v1 = cond_Bt[((long long)(p0 + 16) * 2 * C + n) * KMEL + k];
+    const long long zs = (long long)2 * C * KMEL, o = (long long)p0 * 4 * zs + (long long)n * KMEL + k;
+    V[o] = (float)(v0 + v1);
+    V[o + zs] = (float)(v0 - v1);
+    V[o + 2 * zs] = (float)(v0 / 6.0 + v1 / 12.0);
+    V[o + 3 * zs] = (float)(v0 / 6.0 - v1 / 12.0);
+}
+// mel planes [4][rows][320] (products 1 .. 4): (2/3) m(t) - (1/6) m(t + 1) twice, m(t + 1) - m(t) twice (m(t + 1) = 0 past the end)
+__global__ void wino4_mel_planes_mixed_kernel(const float* __restrict__ mel, float* __restrict__ P, int rows, int BT, int T) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * KMEL) return;
+    const int k = (int)(idx % KMEL);
+    int b, t0;
+    const bool ok = mixed_group(idx / KMEL, BT, T, b, t0);
+    const double m0 = ok ? (double)melwin(mel, (long long)b * T + t0, k, BT, T) : 0.0;
+    const double m1 = ok && t0 + 1 < T ? (double)melwin(mel, (long long)b * T + t0 + 1, k, BT, T) : 0.0;
+    const long long plane = (long long)rows * KMEL;
+    const float a = (float)(m0 * (2.0 / 3.0) - m1 / 6.0), e = (float)(m1 - m0);
+    P[idx] = a;
+    P[plane + idx] = a;
+    P[2 * plane + idx] = e;
+    P[3 * plane + idx] = e;
+}
+
 __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ acts, int d,
                                      int PR, int BT, int T, long long Mq) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -382,6 +325,21 @@ __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* _
     s[1] = b[1] - b[2] + 2.f * (b[3] - b[4]) + bb;
     s[2] = b[1] + b[2] + 4.f * (b[3] + b[4]) + bb;
     s[3] = b[1] - b[2] + 8.f * (b[3] - b[4]) + b[5] + bb;
+    if (d == 16) {                                         // two phases x two frames
+        const int PRm = (int)(Mq / 16);
+        const int p0 = (int)(mg / PRm);
+        int b, t0;
+        if (!mixed_group(mg % PRm, BT, T, b, t0)) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (t0 + (j >> 1) >= T) break;
+            f32x4 g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = gate_tanh_sigmoid(t[j][k], s[j][k]);
+            *reinterpret_cast<f32x4*>(acts + ((long long)(p0 + 16 * (j & 1)) * PR + (long long)b * T + t0 + (j >> 1)) * C + ch) = g;
+        }
+        return;
+    }
     long long r0, rstep;                                   // acts row of output 0 and the row step between outputs
     int nout = 4;                                          // outputs of this group that exist
     if (d < NPH) {
@@ -412,9 +370,12 @@ inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 // Per-layer operands (once, on the first call that takes this path): G, V and the bias planes of layers 1 .. 7 of every flow
-// group rows per phase block of the frame-group layers (dilations >= 32): B x 4 ceil(T / 16), padded to the 128-row tile
+// group rows per block: frame groups (dilations >= 32) B x 4 ceil(T / 16) per phase, mixed groups (dilation 16) B x ceil(T / 2)
+// per p0, both padded to the 128-row tile
 static inline int frame_group_rows(int BT, int T) { return ((BT / T) * frame_groups_per_utt(T) + 127) / 128 * 128; }
+static inline int mixed_group_rows(int BT, int T) { return ((BT / T) * mixed_groups_per_utt(T) + 127) / 128 * 128; }
 
+// Per-layer operands (once, on the first call that takes this path): G and V of layers 1 .. 7 of every flow
 int waveglow_build_wino(tts_hip_engine* e) {
     WaveGlowDev& wg = e->wg;
     if (wg.wino_ready) return TTS_HIP_OK;
@@ -424,28 +385,22 @@ int waveglow_build_wino(tts_hip_engine* e) {
             WgLayerDev& ly = wg.flow[k].layer[i];
             const int d = 1 << i;
             int rc;
-            if (d != 16) {                                 // F(4,3): six products per four outputs
+            if ((rc = dev_alloc(e, (size_t)6 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
+            hipLaunchKernelGGL(wino4_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
+            if (d == 16) {                                 // products 1 .. 4 carry the whole conditioning (K = 320)
+                if ((rc = dev_alloc(e, (size_t)16 * 4 * 2 * C * KMEL, &ly.wino_V, wg.allocs, false))) return rc;
+                hipLaunchKernelGGL(wino4_cond_weights_mixed_kernel, dim3(blocks_for((long long)16 * 2 * C * KMEL)), dim3(256), 0, st,
+                                   ly.cond_Bt, ly.wino_V);
+            } else {
                 const int ngp = d < NPH ? NPH / 4 : NPH;   // weight sets: group phases, or phases
-                if ((rc = dev_alloc(e, (size_t)6 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
                 if ((rc = dev_alloc(e, (size_t)ngp * 6 * 2 * C * K4, &ly.wino_V, wg.allocs, false))) return rc;
-                hipLaunchKernelGGL(wino4_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
                 if (d < NPH)
                     hipLaunchKernelGGL(wino4_cond_weights_kernel, dim3(blocks_for((long long)ngp * 6 * 2 * C * K4)), dim3(256), 0,
                                        st, ly.cond_Bt, ly.wino_V, d);
                 else
                     hipLaunchKernelGGL(wino4_cond_weights_frames_kernel, dim3(blocks_for((long long)ngp * 6 * 2 * C * K4)),
                                        dim3(256), 0, st, ly.cond_Bt, ly.wino_V);
-                HIPCHK(e, hipGetLastError());
-                continue;
             }
-            // d = 16: the four outputs would be two phases x two frames, sharing neither mel rows nor weights -> F(2,3)
-            if ((rc = dev_alloc(e, (size_t)4 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
-            if ((rc = dev_alloc(e, (size_t)(NPH / 2) * 4 * 2 * C * KH, &ly.wino_V, wg.allocs, false))) return rc;
-            if ((rc = dev_alloc(e, (size_t)4 * 2 * C, &ly.wino_bias, wg.allocs, false))) return rc;
-            hipLaunchKernelGGL(wino_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
-            hipLaunchKernelGGL(wino_cond_weights_kernel, dim3(blocks_for((long long)(NPH / 2) * 2 * C * KH)), dim3(256), 0, st,
-                               ly.cond_Bt, ly.wino_V, d);
-            hipLaunchKernelGGL(wino_bias_kernel, dim3(blocks_for(2 * C)), dim3(256), 0, st, ly.in_bias, ly.wino_bias);
             HIPCHK(e, hipGetLastError());
         }
     HIPCHK(e, hipStreamSynchronize(st));
@@ -453,17 +408,17 @@ int waveglow_build_wino(tts_hip_engine* e) {
     return TTS_HIP_OK;
 }
 
-// Layout of the per-call mel planes (floats): [F(2,3): 4][PR][160] | [F(4,3) phases: 6][PR][224] | 3 x [F(4,3) frames: 6][PRq][224]
+// Layout of the per-call mel planes (floats): [phase groups: 6][PR][224] | 3 x [frame groups: 6][PRq][224] | [mixed: 4][PRm][320]
 struct MelPlanes {
-    size_t f23, f43p, f43f[3], total;
+    size_t phases, frames[3], mixed, total;
     MelPlanes(int PR, int BT, int T) {
-        const size_t PRq = (size_t)frame_group_rows(BT, T);
-        f23 = 0;
-        f43p = (size_t)4 * PR * KH;
-        f43f[0] = f43p + (size_t)6 * PR * K4;
-        f43f[1] = f43f[0] + 6 * PRq * K4;
-        f43f[2] = f43f[1] + 6 * PRq * K4;
-        total = f43f[2] + 6 * PRq * K4;
+        const size_t PRq = (size_t)frame_group_rows(BT, T), PRm = (size_t)mixed_group_rows(BT, T);
+        phases = 0;
+        frames[0] = (size_t)6 * PR * K4;
+        frames[1] = frames[0] + 6 * PRq * K4;
+        frames[2] = frames[1] + 6 * PRq * K4;
+        mixed = frames[2] + 6 * PRq * K4;
+        total = mixed + 4 * PRm * KMEL;
     }
 };
 
@@ -471,20 +426,20 @@ struct MelPlanes {
 int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T) {
     WaveGlowDev& wg = e->wg;
     hipStream_t st = e->stream;
-    const long long Mh = (long long)(NPH / 2) * PR;
-    const int PRq = frame_group_rows(BT, T);
-    // U / P planes: F(2,3) 4 x (16 PR) rows, F(4,3) phases 6 x (8 PR), F(4,3) frames 6 x (32 PRq)
-    const size_t rows = (size_t)std::max<long long>(4 * Mh, (long long)6 * NPH * PRq);
+    const int PRq = frame_group_rows(BT, T), PRm = mixed_group_rows(BT, T);
+    // U / P: six planes of 8 PR (phase groups), 32 PRq (frame groups) or 16 PRm (mixed groups) rows
+    const size_t rows = 6 * (size_t)std::max(std::max((long long)(NPH / 4) * PR, (long long)NPH * PRq), (long long)16 * PRm);
     HIPCHK(e, wg.wino_U.ensure(rows * C * 4));
     HIPCHK(e, wg.wino_P.ensure(rows * 2 * C * 4));
     const MelPlanes mp(PR, BT, T);
     HIPCHK(e, wg.wino_mel.ensure(mp.total * 4));
     float* base = wg.wino_mel.f();
-    hipLaunchKernelGGL(wino_mel_planes_kernel, dim3(blocks_for((long long)PR * KH)), dim3(256), 0, st, d_mel, base + mp.f23, PR, BT, T);
-    hipLaunchKernelGGL(wino4_mel_planes_kernel, dim3(blocks_for((long long)PR * K4)), dim3(256), 0, st, d_mel, base + mp.f43p, PR, BT, T);
+    hipLaunchKernelGGL(wino4_mel_planes_kernel, dim3(blocks_for((long long)PR * K4)), dim3(256), 0, st, d_mel, base + mp.phases, PR, BT, T);
     for (int si = 0; si < 3; ++si)
         hipLaunchKernelGGL(wino4_mel_planes_frames_kernel, dim3(blocks_for((long long)6 * PRq * K4)), dim3(256), 0, st, d_mel,
-                           base + mp.f43f[si], 1 << si, PRq, BT, T);
+                           base + mp.frames[si], 1 << si, PRq, BT, T);
+    hipLaunchKernelGGL(wino4_mel_planes_mixed_kernel, dim3(blocks_for((long long)PRm * KMEL)), dim3(256), 0, st, d_mel,
+                       base + mp.mixed, PRm, BT, T);
     HIPCHK(e, hipGetLastError());
     return TTS_HIP_OK;
 }
@@ -497,63 +452,67 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     float* U = wg.wino_U.f();
     float* P = wg.wino_P.f();
     const MelPlanes mp(PR, BT, T);
+    const int PRq = frame_group_rows(BT, T), PRm = mixed_group_rows(BT, T);
+    const bool phases = d <= 8, mixed = d == 16;
+    const long long Mq = phases ? (long long)(NPH / 4) * PR : mixed ? (long long)16 * PRm : (long long)NPH * PRq;
+    hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
     GemmArgs g{};
+    g.M = (int)Mq;
     g.N = 2 * C;
-    g.nseg = 2;
-    g.Bt = ly.wino_G;
+    g.nphase = phases ? NPH / 4 : mixed ? 16 : NPH;
+    g.phase_rows = phases ? PR : mixed ? PRm : PRq;
+    g.frames = phases ? BT : mixed ? (BT / T) * mixed_groups_per_utt(T) : (BT / T) * frame_groups_per_utt(T);
+    g.L = g.phase_rows;
     g.ldb = C;
-    g.strideBz = (long long)2 * C * C;
-    g.Bt2 = ly.wino_V;
     g.mode = EPI_LINEAR;
     g.act = ACT_NONE;
     g.split = 2 * C;
-    g.out0 = P;
     g.ld0 = 2 * C;
     g.wide_epi = 1;
-    if (d != 16) {                                         // F(4,3): groups of four phases (d <= 8) or of four frames (d >= 32)
-        const bool phases = d < NPH;
-        const int PRq = frame_group_rows(BT, T);
-        const long long Mq = phases ? (long long)(NPH / 4) * PR : (long long)NPH * PRq;
-        hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
-        g.M = (int)Mq;
-        g.nphase = phases ? NPH / 4 : NPH;
-        g.phase_rows = phases ? PR : PRq;
-        g.frames = phases ? BT : (BT / T) * frame_groups_per_utt(T);
-        g.L = g.phase_rows;
-        const float* mel6 = wg.wino_mel.f() + (phases ? mp.f43p : mp.f43f[i - 5]);
+    const long long uplane = Mq * C, gplane = (long long)2 * C * C, pplane = Mq * 2 * C;
+    if (!mixed) {                                          // six slices of K = 512 + 224
+        g.nseg = 2;
         g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mq, 1};
-        g.seg[1] = ASeg{mel6, K4, 0, K4, K4, SEG_FRAME_Z, 0, (long long)g.phase_rows, 0};
+        g.seg[1] = ASeg{wg.wino_mel.f() + (phases ? mp.phases : mp.frames[i - 5]), K4, 0, K4, K4, SEG_FRAME_Z, 0, (long long)g.phase_rows, 0};
+        g.Bt = ly.wino_G;
+        g.strideBz = gplane;
+        g.Bt2 = ly.wino_V;
         g.ldb2 = K4;
         g.strideB2p = (long long)6 * 2 * C * K4;
         g.strideB2z = (long long)2 * C * K4;
-        g.strideOutZ = Mq * 2 * C;
+        g.out0 = P;
+        g.strideOutZ = pplane;
         timing_begin(e, 0);
         HIPCHK(e, phases ? gemm_wn_wino(g, 6, st) : gemm_wn_wino_128(g, 6, st));
         timing_end(e);
-        hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, BT, T, Mq);
-        HIPCHK(e, hipGetLastError());
-        return TTS_HIP_OK;
+    } else {
+        // products 1 .. 4: K = 512 + 320 (they carry the whole conditioning) ...
+        g.nseg = 2;
+        g.seg[0] = ASeg{U + uplane, C, 0, C, C, SEG_ROWS_Z, 0, Mq, 1};
+        g.seg[1] = ASeg{wg.wino_mel.f() + mp.mixed, KMEL, 0, KMEL, KMEL, SEG_FRAME_Z, 0, (long long)PRm, 0};
+        g.Bt = ly.wino_G + gplane;
+        g.strideBz = gplane;
+        g.Bt2 = ly.wino_V;
+        g.ldb2 = KMEL;
+        g.strideB2p = (long long)4 * 2 * C * KMEL;
+        g.strideB2z = (long long)2 * C * KMEL;
+        g.out0 = P + pplane;
+        g.strideOutZ = pplane;
+        timing_begin(e, 0);
+        HIPCHK(e, gemm_wn_wino_128(g, 4, st));
+        timing_end(e);
+        // ... products 0 and 5: K = 512, planes 0 and 5 (z stride of five planes)
+        GemmArgs h = g;
+        h.nseg = 1;
+        h.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, 5 * Mq, 0};
+        h.Bt = ly.wino_G;
+        h.strideBz = 5 * gplane;
+        h.Bt2 = nullptr;
+        h.out0 = P;
+        h.strideOutZ = 5 * pplane;
+        HIPCHK(e, gemm_wn_wino_128(h, 2, st));
     }
-    // d = 16: F(2,3) on pairs of phases (p0, p0 + 16)
-    const long long Mh = (long long)(NPH / 2) * PR;
-    hipLaunchKernelGGL(wino_prepass_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mh);
-    g.M = (int)Mh;
-    g.nphase = NPH / 2;
-    g.phase_rows = PR;
-    g.frames = BT;
-    g.L = PR;
-    g.seg[0] = ASeg{U, C, 0, C, C, SEG_ROWS_Z, 0, Mh, 1};
-    g.seg[1] = ASeg{wg.wino_mel.f() + mp.f23, KH, 0, KH, KH, SEG_FRAME_Z, 0, (long long)PR, 0};
-    g.ldb2 = KH;
-    g.strideB2p = (long long)4 * 2 * C * KH;
-    g.strideB2z = (long long)2 * C * KH;
-    g.bias = ly.wino_bias;
-    g.strideBiasZ = 2 * C;
-    g.strideOutZ = Mh * 2 * C;
-    timing_begin(e, 0);
-    HIPCHK(e, gemm_wn_wino(g, 4, st));
-    timing_end(e);
-    hipLaunchKernelGGL(wino_combine_kernel, dim3(blocks_for(Mh * (C / 4))), dim3(256), 0, st, P, acts_i, d, PR, Mh);
+    hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, BT, T, Mq);
     HIPCHK(e, hipGetLastError());
     return TTS_HIP_OK;
 }
