@@ -52,16 +52,18 @@ K_REFERENCE = 3 * 512 + 640        # the reference formulation: taps + 640-chann
 
 
 def wino_in_layer_flops(B: int, T: int) -> float:
-    """FLOPs the Winograd form of the in-layer GEMM EXECUTES per launch, averaged over the 7 launches of a flow
-    (csrc/wn_wino.hip): F(4,3) = six K = 512 + 224 products on M / 4 group rows for the dilations 2, 4, 8 (groups of phases)
-    and 32, 64, 128 (groups of frames: group rows per phase padded to the 128-row tile), F(2,3) = four K = 512 + 160 products
-    on M / 2 pair rows for dilation 16."""
-    PR = (B * T + 255) // 256 * 256                      # frame rows per phase block (256-row tiles)
-    PRq = (PR // 4 + 127) // 128 * 128
-    f43_phases = 6 * (8 * PR) * (512 + 224)
-    f43_frames = 6 * (32 * PRq) * (512 + 224)
-    f23 = 4 * (16 * PR) * (512 + 160)
-    return 2.0 * 1024 * (3 * f43_phases + 3 * f43_frames + f23) / 7.0
+    """FLOPs the Winograd form of the in-layer GEMM EXECUTES per launch, averaged over the 8 launches of a flow
+    (csrc/wn_wino.hip, F(4,3)): six K = 512 + 224 products on M / 4 group rows for the dilations 2, 4, 8 (groups of phases)
+    and 32, 64, 128 (groups of frames, group rows per phase padded to the 128-row tile); dilation 16 (two phases x two
+    frames) = four K = 512 + 320 products and, in a second launch, two K = 512 products."""
+    BT = B * T
+    PR = (BT + 255) // 256 * 256                         # frame rows per phase block (256-row tiles)
+    PRq = (B * ((T + 15) // 16 * 4) + 127) // 128 * 128
+    PRm = (B * ((T + 1) // 2) + 127) // 128 * 128
+    phases = 6 * (8 * PR) * (512 + 224)
+    frames = 6 * (32 * PRq) * (512 + 224)
+    mixed = 4 * (16 * PRm) * (512 + 320) + 2 * (16 * PRm) * 512
+    return 2.0 * 1024 * (3 * phases + 3 * frames + mixed) / 8.0
 
 
 def wn_in_layer_flops(M: int, k: int = K_EXECUTED) -> float:
@@ -442,17 +444,17 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                     'avg_launch_us': avg_us,
                     'kernel': 'WN in-layer implicit GEMM, fp16 MFMA (' + args.precision + ')'}
     elif launches:
-        # `achieved` prices the FLOPs the timed kernel EXECUTES: the Winograd form ~K = 1160 per output (wino_in_layer_flops),
+        # `achieved` prices the FLOPs the timed kernel EXECUTES: the Winograd form ~K = 1120 per output (wino_in_layer_flops),
         # the direct form K = 1536 + 320
         wino = form == 'winograd'
         flops = wino_in_layer_flops(B, T) if wino else wn_in_layer_flops(M)
         achieved = flops / (avg_us * 1e-6) / 1e12
         if wino:
             kernel = ('gemm_f32_kernel<4,1,{2|1},4,16,{2|3},TAG_WN_WINO=4,0,PIPE_DMA>, one z slice per Winograd product (WN in-layer '
-                      'GEMM of layers 1-7: F(4,3) = six K = 512 + 224 products on M / 4 group rows for dilations 2, 4, 8 (256-row '
-                      'tiles) and 32, 64, 128 (128-row tiles), F(2,3) = four K = 512 + 160 products on M / 2 pair rows for dilation '
-                      '16; average over the 7 launches of a flow; the pre-pass and the combine + gate pass are separate HBM-bound '
-                      'kernels)')
+                      'GEMM of layers 1-7 in its F(4,3) form: six K = 512 + 224 products on M / 4 group rows -- 256-row tiles for the '
+                      'phase groups of dilations 2, 4, 8, 128-row tiles for the frame groups of dilations 32, 64, 128; dilation 16: '
+                      'four K = 512 + 320 products + two K = 512 products in two launches; average over the 8 launches of a flow; '
+                      'the pre-pass and the combine + gate pass are separate HBM-bound kernels)')
             # per launch (F(4,3)): six transformed-input planes in, six product planes out, weights
             alg_bytes = (6 * (M // 4) * 512 + 6 * (M // 4) * 1024 + 6 * 1024 * 512 + 8 * 6 * 1024 * 224) * 4.0
         else:
@@ -480,7 +482,7 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                    'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
                    'weights': 'seeded synthetic (rng 1234)',
                    'arithmetic': 'fp32 operands, fp32 MFMA accumulate; dilated convolutions of WN layers 1-7 in their '
-                                 + ('Winograd form along the tap axis (csrc/wn_wino.hip: F(4,3), F(2,3) for dilation 16; 5.9e-7 '
+                                 + ('Winograd F(4,3) form along the tap axis (csrc/wn_wino.hip; 6.0e-7 '
                                     'waveform RMS error against the oracle, the direct form 4.96e-7: tests/test_waveglow_gpu.py)'
                                     if form == 'winograd'
                                     else 'direct three-tap form')},

@@ -152,7 +152,7 @@ def test_waveglow_256_row_tiles_match_oracle(gpu_engine, wg_weights, wg_cfg):
 
 
 def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_weights, wg_cfg):
-    """The fp32 path evaluates WN layers 1 - 7 in their Winograd form (F(4,3); F(2,3) for dilation 16) when the call takes the
+    """The fp32 path evaluates WN layers 1 - 7 in their Winograd F(4,3) form when the call takes the
     256-row tiles (csrc/wn_wino.hip): both forms against the oracle on the same inputs, the switch, the report of which one ran,
     utterance lengths that leave partial frame groups, and the small shapes that keep the direct form."""
     from oracle import waveglow_ref

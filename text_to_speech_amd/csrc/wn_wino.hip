@@ -1,35 +1,33 @@
-// wn_wino.hip -- Winograd minimal filtering along the tap axis of the WN dilated convolution (fp32 path, 256-row tiles).
+// wn_wino.hip -- Winograd minimal filtering F(4,3) along the tap axis of the WN dilated convolution (fp32 path, 256-row tiles).
 //
 // The in-layer pre-activation of WaveGlow's WN (/root/reference/architectures/waveglow_arch.py:117-127) is a k = 3 dilated
-// convolution plus the conditioning term,  y[l] = W- x[l - d] + W0 x[l] + W+ x[l + d] + c[l] + b.  Outputs one dilation apart
-// share inputs, so NO outputs y[l], y[l + d], ... need only NO + 2 products instead of 3 NO:
+// convolution plus the conditioning term,  y[l] = W- x[l - d] + W0 x[l] + W+ x[l + d] + c[l] + b.  The FOUR outputs
+// y[l], y[l + d], y[l + 2d], y[l + 3d] share the six inputs x[l - d] ... x[l + 4d] and need only SIX K = 512 products
+// instead of twelve (K per output 768 instead of 1536), and the six products are ONE launch of the GEMM kernel of gemm_f32.h:
+// one blockIdx.z slice per product on M / 4 "group rows", operand planes U[z] against weight planes G[z].  Three passes per
+// layer:
 //
-//   F(4,3)  six products per FOUR outputs (K per output 768 instead of 1536; dilations 2, 4, 8, 32, 64, 128; see below)
-//   F(2,3)  four products per TWO outputs (K per output 1024; dilation 16)
-//
-// and the NO + 2 products are ONE launch of the GEMM kernel of gemm_f32.h: one blockIdx.z slice per product on M / NO "group
-// rows", operand planes U[z] against weight planes G[z].  Three passes per layer:
-//
-//   pre-pass   x -> U[NO + 2][M / NO][512]     (the transformed inputs; HBM-bound)
+//   pre-pass   x -> U[6][M / 4][512]           (the transformed inputs; HBM-bound)
 //   GEMM       P[z] = U[z] G[z]^T + melP[z] V[z]^T
-//   combine    y_j = sum_z AT[j][z] P[z] (+ b),  acts = tanh(.) * sigmoid(.)  written to the NO output rows
+//   combine    y_j = sum_z AT[j][z] P[z] + b,  acts = tanh(.) * sigmoid(.)  written to the four output rows
 //
-// The conditioning term (K = 320 per output) is spread over the products so that none idles.  F(2,3): its first half goes
-// into the products that feed one output only (m0, -m3) and, with c0 = s + e, c1 = s - e, the second half as s into m1 and as e
-// into m2: K = 512 + 160 per product.  F(4,3): three K slices A = [0, 112), B = [112, 208), C = [208, 320), each carried by a
-// product subset whose columns of the output transform AT have rank 4 -- {0, 1, 2, 5}, {0, 3, 4, 5}, {1, 2, 3, 4} -- and
-// combined with the inverse of those columns: K = 512 + 224 per product (208 padded to 224 for products 0, 3, 4, 5).
+// The conditioning term (K = 320 per output) is spread over the products so that none idles: three K slices A = [0, 112),
+// B = [112, 208), C = [208, 320), each carried by a product subset whose columns of the output transform AT have rank 4 --
+// {0, 1, 2, 5}, {0, 3, 4, 5}, {1, 2, 3, 4} -- and combined with the inverse of those columns: K = 512 + 224 per product (208
+// padded to 224 for products 0, 3, 4, 5).
 //
 // Groups.  Dilation d <= 8 (sample groups): four PHASES p0 + j d of one frame, 8 group phases p0 = (gp / d) 4d + gp % d; the
 // outputs share their mel rows and differ in the per-phase conditioning weights, so the slice combinations are WEIGHT
-// combinations built at load.  d >= 32 (s = d / 32 frames): four FRAMES f0 + j s of one phase, f0 = (gf / s) 4s + gf % s; the
-// outputs share the weights and the combinations are MEL combinations built once per call (group rows per phase padded to
-// the 128-row tile).  d = 16: four outputs would be two phases x two frames and share neither, so that layer runs F(2,3) on
-// the 16 phase pairs (p0, p0 + 16).  Frame groups are cut per utterance (frame_group below), so any utterance length works.
+// combinations built at load.  d >= 32 (s = d / 32 frames): four FRAMES t0 + j s of one phase; the outputs share the weights
+// and the combinations are MEL combinations built once per call.  d = 16: two phases x two frames, sharing neither -- but
+// every row of subset {1, 2, 3, 4}'s coefficient matrix is an outer product (over the two frames) x (over the two phases),
+// so those four products carry the WHOLE conditioning as one mel combination times one weight combination each (K = 512 +
+// 320, first launch) and products 0 and 5 run K = 512 (second launch): the same K per output.  Frame groups are cut per
+// utterance, so any utterance length works.
 //
 // Numerics: every operand stays fp32, weight / mel combinations are formed in fp64 and rounded once.  F(4,3)'s transform
-// constants (4, 5, 8, 1/6, 1/24) cost accuracy: error of one layer ~3x the direct form's (F(2,3): 1.3x); end to end against
-// the oracle 5.9e-7 waveform RMS (direct form 4.96e-7; tolerance 1e-4).  Not bit-identical to the direct form.
+// constants (4, 5, 8, 1/6, 1/24) cost accuracy: error of one layer ~3x the direct form's; end to end against the oracle
+// 6.0e-7 waveform RMS (direct form 4.96e-7; tolerance 1e-4).  Not bit-identical to the direct form.
 #include "engine.h"
 #include "gemm_f32.h"
 
@@ -510,7 +508,9 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
         h.Bt2 = nullptr;
         h.out0 = P;
         h.strideOutZ = 5 * pplane;
+        timing_begin(e, 0);
         HIPCHK(e, gemm_wn_wino_128(h, 2, st));
+        timing_end(e);
     }
     hipLaunchKernelGGL(wino4_combine_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, P, ly.in_bias, acts_i, d, PR, BT, T, Mq);
     HIPCHK(e, hipGetLastError());

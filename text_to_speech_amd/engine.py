@@ -422,7 +422,7 @@ class HipEngine:
 
     def set_waveglow_form(self, form: str) -> None:
         """How the fp32 vocoder evaluates the dilated convolutions of WN layers 1 - 7: 'winograd' (default: minimal filtering
-        along the tap axis -- F(4,3), F(2,3) for dilation 16 -- whenever the call is large enough for the 256-row tiles, from
+        along the tap axis, F(4,3), whenever the call is large enough for the 256-row tiles, from
         about 700 frames per call) or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
         forms = {'direct': 0, 'winograd': 1}
         if form not in forms:
