@@ -152,11 +152,11 @@ def test_waveglow_256_row_tiles_match_oracle(gpu_engine, wg_weights, wg_cfg):
 
 
 def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_weights, wg_cfg):
-    """The fp32 path evaluates WN layers 1 - 7 in their Winograd F(4,3) form when the call takes the
-    256-row tiles (csrc/wn_wino.hip): both forms against the oracle on the same inputs, the switch, the report of which one ran,
-    utterance lengths that leave partial frame groups, and the small shapes that keep the direct form."""
+    """The fp32 path evaluates WN layers 1 - 7 in their Winograd F(4,3) form from 384 frames per call (csrc/wn_wino.hip): both
+    forms against the oracle on the same inputs, the switch, the report of which one ran, utterance lengths that leave partial
+    frame groups, and the small shapes that keep the direct form."""
     from oracle import waveglow_ref
-    mel, z = _inputs(2, 128, seed=33)
+    mel, z = _inputs(2, 192, seed=33)                              # 384 frames: the smallest call that takes the Winograd form
     ref = waveglow_ref.infer(mel, wg_weights, wg_cfg, z=z, sigma=1.0)
     try:
         wino = gpu_engine.waveglow_infer(mel, z=z, sigma=1.0)
@@ -169,19 +169,20 @@ def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_we
     e_w, e_d, diff = rms(wino - ref), rms(direct - ref), rms(wino - direct)
     print(f'winograd rms_err={e_w:.3e}  direct rms_err={e_d:.3e}  winograd vs direct {diff:.3e}')
     assert e_w <= RMS_TOL and e_d <= RMS_TOL and diff <= 5e-6
-    # utterance lengths that are not a multiple of the group sizes (2 x 126 and 2 x 121 frames, same 256-row tiles): the frame
-    # groups are cut per utterance (the last group of an utterance is partial), so these run the Winograd form as well
-    for T2, seed in ((126, 34), (121, 36)):
-        mel2, z2 = _inputs(2, T2, seed=seed)
+    # utterance lengths that are not a multiple of the group sizes (2 x 195 and 3 x 131 frames): the frame groups are cut per
+    # utterance (the last group of an utterance is partial), so these run the Winograd form as well
+    for B2, T2, seed in ((2, 195, 34), (3, 131, 36)):
+        mel2, z2 = _inputs(B2, T2, seed=seed)
         out2 = gpu_engine.waveglow_infer(mel2, z=z2, sigma=1.0)
         assert gpu_engine.last_waveglow_form == 'winograd'
         e2 = rms(out2 - waveglow_ref.infer(mel2, wg_weights, wg_cfg, z=z2, sigma=1.0))
-        print(f'2 x {T2} frames: winograd rms_err={e2:.3e}')
+        print(f'{B2} x {T2} frames: winograd rms_err={e2:.3e}')
         assert e2 <= RMS_TOL
-    # small calls (64- / 128-row tiles) always take the direct form; the fp16 modes have no Winograd form
-    m3, z3 = _inputs(1, 16, seed=35)
-    gpu_engine.waveglow_infer(m3, z=z3)
-    assert gpu_engine.last_waveglow_form == 'direct'
+    # calls below 384 frames keep the direct form (the Winograd form's extra passes cost more than its products save)
+    for B3, T3 in ((1, 16), (2, 128)):
+        m3, z3 = _inputs(B3, T3, seed=35)
+        gpu_engine.waveglow_infer(m3, z=z3)
+        assert gpu_engine.last_waveglow_form == 'direct'
     with pytest.raises(ValueError):
         gpu_engine.set_waveglow_form('fft')
 

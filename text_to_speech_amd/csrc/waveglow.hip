@@ -737,13 +737,14 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     bool row64 = x3 ? pr64 * 1.25 < pr256      // split fp16 has two tile shapes: 64 x 128 (about 25 % more time per row) and 256 x 256
                     : BT <= 512 &&
                       (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
-    // fp32: the Winograd form (wn_wino.hip) only exists on the 256-row tiles and executes K ~1 160 per output instead of
-    // 1 856, so a call whose rows would pad better on smaller tiles still takes the 256-row tiles when that is clearly less
-    // work (its two HBM-bound passes and the shorter tiles priced at +35 %: one sentence of 800 frames 85.1 -> 71.9 ms, 513
-    // or 600 frames break even and keep the smaller tiles)
-    if (precision == 0 && wg.form_mode == 1 && (tile128 || row64)) {
-        const double direct = (double)(row64 ? pr64 : pr128) * 1856.0, wino256 = (double)pr256 * 1160.0 * 1.35;
-        if (wino256 < direct) tile128 = row64 = false;
+    // fp32: the Winograd form (wn_wino.hip) runs on 128- or 256-row tiles and executes K ~1 120 per output instead of 1 856.
+    // It pays from about 350 frames per call (one sentence, measured: 400 frames 44.4 -> 38.2 ms, 513: 61.2 -> 55.6, 800: 84.7 ->
+    // 67.2; 300 frames break even, 100 frames lose 40 % to its two HBM-bound passes and six-slice launches); a call of that
+    // size whose rows would pad better on 64-row tiles takes the 128-row tiles when that is clearly less work
+    const bool wino_size = precision == 0 && wg.form_mode == 1 && BT >= 384;
+    if (wino_size && row64 && (double)pr128 * 1120.0 * 1.35 < (double)pr64 * 1856.0) {
+        row64 = false;
+        tile128 = pr128 * 1.05 < pr256;
     }
     const int PR = row64 ? pr64 : (tile128 && !x3) ? pr128 : pr256;
     const int NP = x3 ? 2 : 1;                                   // fp16 planes per operand
@@ -764,8 +765,8 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         HIPCHK(e, wg.a0p.ensure((size_t)M * 16 * 4));
     }
     hipStream_t st = e->stream;
-    // exact-fp32 path, 256-row tiles: layers 1 .. 7 of a flow run in their Winograd form (wn_wino.hip)
-    bool wino = precision == 0 && !row64 && !tile128 && !tile64 && wg.form_mode == 1;
+    // fp32 path, 128- / 256-row tiles: layers 1 .. 7 of a flow run in their Winograd form (wn_wino.hip)
+    bool wino = wino_size && !row64;                                      // (PR is a multiple of 128)
     if (wino) {
         // its operands (6.4 GB of weight planes on first use, 2.6 GB of workspace at config 2) are extra: when the device
         // cannot hold them this handle keeps the direct form from now on instead of failing the call

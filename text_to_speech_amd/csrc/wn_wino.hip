@@ -1,4 +1,4 @@
-// wn_wino.hip -- Winograd minimal filtering F(4,3) along the tap axis of the WN dilated convolution (fp32 path, 256-row tiles).
+// wn_wino.hip -- Winograd minimal filtering F(4,3) along the tap axis of the WN dilated convolution (fp32 path, 128- / 256-row tiles).
 //
 // The in-layer pre-activation of WaveGlow's WN (/root/reference/architectures/waveglow_arch.py:117-127) is a k = 3 dilated
 // convolution plus the conditioning term,  y[l] = W- x[l - d] + W0 x[l] + W+ x[l + d] + c[l] + b.  The FOUR outputs
@@ -481,7 +481,7 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
         g.out0 = P;
         g.strideOutZ = pplane;
         timing_begin(e, 0);
-        HIPCHK(e, phases ? gemm_wn_wino(g, 6, st) : gemm_wn_wino_128(g, 6, st));
+        HIPCHK(e, phases && PR % 256 == 0 ? gemm_wn_wino(g, 6, st) : gemm_wn_wino_128(g, 6, st));
         timing_end(e);
     } else {
         // products 1 .. 4: K = 512 + 320 (they carry the whole conditioning) ...

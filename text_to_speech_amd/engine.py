@@ -422,8 +422,7 @@ class HipEngine:
 
     def set_waveglow_form(self, form: str) -> None:
         """How the fp32 vocoder evaluates the dilated convolutions of WN layers 1 - 7: 'winograd' (default: minimal filtering
-        along the tap axis, F(4,3), whenever the call is large enough for the 256-row tiles, from
-        about 700 frames per call) or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
+        along the tap axis, F(4,3), for calls of 384 frames or more) or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
         forms = {'direct': 0, 'winograd': 1}
         if form not in forms:
             raise ValueError(f'form must be one of {tuple(forms)}, got {form!r}')
