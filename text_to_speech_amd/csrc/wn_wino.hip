@@ -59,19 +59,18 @@ __device__ __forceinline__ float melwin(const float* __restrict__ mel, long long
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// F(4,3) for the dilations 2, 4, 8 (four outputs l, l + d, l + 2d, l + 3d = four phases of one frame, 8 "group phases"
-// p0 = (gp / d) 4d + gp % d): six K = 512 products per FOUR outputs (K per output 768 instead of 1024 / 1536).  With the six
-// inputs x_i = x[l + (i - 1) d] (Lavin & Gray's F(4,3); fp32 error ~3x the direct form's, far inside the tolerance):
+// The transforms (Lavin & Gray's F(4,3); fp32 error ~3x the direct form's, far inside the tolerance), with the six inputs
+// x_i = x[l + (i - 1) d] of the four outputs l, l + d, l + 2d, l + 3d:
 //   U0 = 4 x0 - 5 x2 + x4            G0 = W- / 4                          y0 = P0 + P1 + P2 + P3 + P4
 //   U1 = -4 x1 - 4 x2 + x3 + x4      G1 = -(W- + W0 + W+) / 6             y1 = P1 - P2 + 2 P3 - 2 P4
 //   U2 = 4 x1 - 4 x2 - x3 + x4       G2 = -(W- - W0 + W+) / 6             y2 = P1 + P2 + 4 P3 + 4 P4
 //   U3 = -2 x1 - x2 + 2 x3 + x4      G3 = W- / 24 + W0 / 12 + W+ / 6      y3 = P1 - P2 + 8 P3 - 8 P4 + P5
 //   U4 = 2 x1 - x2 - 2 x3 + x4       G4 = W- / 24 - W0 / 12 + W+ / 6
 //   U5 = 4 x1 - 5 x3 + x5            G5 = W+
-// The conditioning (same mel rows for the four outputs, four per-phase weight sets V_j) is cut into three K slices, each
-// carried by a product subset whose columns of the output transform have rank 4 -- A = [0, 112) on {0, 1, 2, 5}, B = [112, 208)
-// on {0, 3, 4, 5}, C = [208, 320) on {1, 2, 3, 4} -- with the weights combined by the inverse of those columns, so that every
-// product runs K = 512 + 224 (208 padded to 224 for products 0, 3, 4, 5).  The bias is added in the combine pass.
+// Phase and frame groups: the conditioning is cut into three K slices, each carried by a product subset whose columns of the
+// output transform have rank 4 -- A = [0, 112) on {0, 1, 2, 5}, B = [112, 208) on {0, 3, 4, 5}, C = [208, 320) on {1, 2, 3, 4} --
+// and combined by the inverse of those columns (W4_A / W4_B / W4_C below), so that every product runs K = 512 + 224 (208 padded
+// to 224 for products 0, 3, 4, 5).  The bias is added in the combine pass.
 constexpr int K4 = 224, SA = 112, SB = 96, SC = 112;       // conditioning K of a product; slice widths (A, B, C)
 
 __device__ __forceinline__ int group_phase0(int gp, int d) { return (gp / d) * 4 * d + gp % d; }
