@@ -600,7 +600,11 @@ def main():
         if rank == 0 and headline['ready']:
             headline['result']['config4_sharded_job'] = {'error': f'no result after {CONFIG4_TIMEOUT_S} s (cut off by the watchdog)'}
             print(json.dumps(headline['result']), flush=True)
-        os._exit(0 if headline['ready'] or rank != 0 else 1)
+        # a rank stuck in a GPU collective is a FAILED run: the line (when there is one) is out, the status says so
+        # (launch_ranks returns the worst child status), and nothing is retried in this process
+        sys.stderr.write(f'[bench rank {rank}] config-4 job hung: no result after {CONFIG4_TIMEOUT_S} s; exiting with status 3\n')
+        sys.stderr.flush()
+        os._exit(3)
     if not args.no_config4:
         import threading
         if rank == 0:
@@ -626,7 +630,11 @@ def main():
     if distributed:
         # the line is out: a rank that is gone must not keep the others (and the driver) at this barrier
         import threading
-        bye = threading.Timer(60, lambda: os._exit(0))
+        def stuck_at_exit():
+            sys.stderr.write(f'[bench rank {rank}] final barrier not reached by every rank within 60 s; exiting with status 4\n')
+            sys.stderr.flush()
+            os._exit(4)
+        bye = threading.Timer(60, stuck_at_exit)
         bye.daemon = True
         bye.start()
         dist.barrier()

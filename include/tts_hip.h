@@ -181,6 +181,13 @@ int tts_hip_set_waveglow_form(tts_hip_engine* e, int form);
 /* Which one the last tts_hip_waveglow_infer* call on this handle used: 1 Winograd, 0 direct, -1 before the first call.  */
 int tts_hip_last_waveglow_form(const tts_hip_engine* e);
 
+/* Test hook (used by tests/ only; no effect on later calls): runs the fp32 path of tts_hip_waveglow_infer -- in the form
+ * selected by tts_hip_set_waveglow_form -- up to WN layer `layer` (0 .. 7) of flow `flow` (flows run 11 .. 0) and copies that
+ * layer's gated activations tanh(.) * sigmoid(.) (waveglow_arch.py:19-24,117-127), i.e. the values BEFORE the res/skip and
+ * `end` convolutions attenuate an error, to `acts` [B, T*32, 512] in the reference's position order.  B*T <= 31744.       */
+int tts_hip_waveglow_probe_acts(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma, int flow,
+                                int layer, float* acts, int mem);
+
 /* ---- TacotronSTFT.mel_spectrogram  (utils/audio/stft.py:242-274,306-314)
  * audio [B, N] (N >= 1024) -> mel [B, N/256 + 1, 80]                                                                */
 int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float* mel, int mem);

@@ -61,8 +61,12 @@ def conv1d_dilated_same(x, kernel, bias, dilation):
     return out
 
 
-def wn_block(a0, spect, w, prefix, n_layers=8, n_channels=512):
-    """WaveglowBlock.call (non-fused variant).  waveglow_arch.py:105-141."""
+def wn_block(a0, spect, w, prefix, n_layers=8, n_channels=512, collect=None, stop_after=None):
+    """WaveglowBlock.call (non-fused variant).  waveglow_arch.py:105-141.
+
+    `collect` (a list): the gated activations `acts` of every layer (waveglow_arch.py:19-24) are appended to it -- what the
+    layer-level parity tests compare, before the res/skip and `end` convolutions attenuate an error; `stop_after`: return
+    None after that layer (the tests only need the first layers of one flow)."""
     x = a0 @ w[f'{prefix}/start_conv/kernel'][0] + w[f'{prefix}/start_conv/bias']
     output = None
     for i in range(n_layers):
@@ -71,6 +75,10 @@ def wn_block(a0, spect, w, prefix, n_layers=8, n_channels=512):
         cond = spect @ w[f'{prefix}/cond_layer-{i}/kernel'][0] + w[f'{prefix}/cond_layer-{i}/bias']
         s = in_act + cond
         acts = np.tanh(s[..., :n_channels]) * _sigmoid(s[..., n_channels:])
+        if collect is not None:
+            collect.append(acts)
+        if stop_after is not None and i >= stop_after:
+            return None
         rs = acts @ w[f'{prefix}/res_skip_conv-{i}/kernel'][0] + w[f'{prefix}/res_skip_conv-{i}/bias']
         if i < n_layers - 1:
             x = rs[..., :n_channels] + x

@@ -188,7 +188,8 @@ def test_prenet_masks_drawn_on_the_device(gpu_engine, taco_weights, taco_cfg):
             gpu_engine.set_decoder_mode('auto')
     rt = HipRuntime('unused', engine=gpu_engine, model='tacotron2', seed=41)
     first = rt(tok, max_length=T, early_stopping=False)                    # offset 0 of seed 41
-    m0 = philox_ref.prenet_masks(3 * T * 512, 41, 0).reshape(3, T, 2, 256)
+    from text_to_speech_amd.runtime import MASK_STREAM                     # the runtime's dropout key: seed ^ purpose constant
+    m0 = philox_ref.prenet_masks(3 * T * 512, 41 ^ MASK_STREAM, 0).reshape(3, T, 2, 256)
     ref0 = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=T, early_stopping=False, prenet_masks=m0)
     assert np.abs(first.mel - ref0.mel).max() <= 1e-3
     second = rt(tok, max_length=T, early_stopping=False)                   # a retry: same encoder output, other masks
@@ -215,6 +216,39 @@ def test_runtime_reuses_one_encoded_batch_handle_across_sentences(gpu_engine, ta
         assert len(handles) == 1 and rt.encoder_reuses == 0
     finally:
         gpu_engine.set_decoder_mode('auto')
+
+
+def test_runtime_never_reuses_the_encoder_for_other_device_tokens(gpu_engine, taco_weights, taco_cfg):
+    """Round-3 advisor finding: the encoder-reuse key of DEVICE inputs was (address, version, shape).  A caller that builds a
+    fresh int64 token tensor per sentence gets the freed tensor's address back from torch's caching allocator -- same key,
+    other tokens -- and the decoder ran on the previous sentence's encoder output.  The key compares contents now: two
+    different sentences of one shape, each created, used and freed back to back, must each match the oracle; the same
+    sentence again (the reference's retry, models/tts/tacotron2.py:160-179) must still reuse the encoder, also from a
+    re-created tensor and after an in-place change of the caller's tensor has been undone."""
+    import torch
+    from oracle import tacotron2_ref
+    from text_to_speech_amd.runtime import HipRuntime
+    rt = HipRuntime('unused', engine=gpu_engine, model='tacotron2')
+    toks = [_tokens(1, 40, [40], seed=200 + i) for i in range(3)]
+    refs = [tacotron2_ref.infer(t, taco_weights, taco_cfg, max_length=16, early_stopping=False) for t in toks]
+    ptrs = set()
+    for t, ref in zip(toks, refs):
+        dev_tok = torch.from_numpy(t.astype(np.int64)).cuda()           # torch's default integer type: a new tensor per sentence
+        ptrs.add(dev_tok.data_ptr())
+        out = rt(dev_tok, max_length=16, early_stopping=False, deterministic=True)
+        assert np.abs(out.mel.cpu().numpy() - ref.mel).max() <= 1e-3
+        del dev_tok, out
+    print(f'{len(ptrs)} distinct token addresses over 3 sentences')     # (1 when the allocator recycles the block)
+    assert rt.encoder_reuses == 0
+    again = torch.from_numpy(toks[2].astype(np.int64)).cuda()           # same sentence, new tensor: the encoder is reused
+    out = rt(again, max_length=16, early_stopping=False, deterministic=True)
+    assert rt.encoder_reuses == 1 and np.abs(out.mel.cpu().numpy() - refs[2].mel).max() <= 1e-3
+    again[0, 3] = (int(again[0, 3]) % 147) + 1                          # changed in place: another sentence at the same address
+    changed = toks[2].copy()
+    changed[0, 3] = int(again[0, 3])
+    out = rt(again, max_length=16, early_stopping=False, deterministic=True)
+    ref_c = tacotron2_ref.infer(changed, taco_weights, taco_cfg, max_length=16, early_stopping=False)
+    assert rt.encoder_reuses == 1 and np.abs(out.mel.cpu().numpy() - ref_c.mel).max() <= 1e-3
 
 
 def test_two_handles_on_the_fused_step_take_turns(gpu_engine, taco_weights):

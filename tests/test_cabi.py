@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_null_handle_errors(lib):
-    assert lib.tts_hip_abi_version() == 9
+    assert lib.tts_hip_abi_version() == 10
     assert lib.tts_hip_destroy(None) == -1                       # TTS_HIP_EINVAL, no crash
     assert lib.tts_hip_finalize(None) == -1
     assert lib.tts_hip_has_model(None, b'waveglow') == 0
@@ -64,12 +64,7 @@ def _check_file(lib, path):
     return rc, buf.value.decode()
 
 
-def _small_ttsw(tmp_path):
-    import numpy as np
-    from text_to_speech_amd import weights
-    p = tmp_path / 'ok.ttsw'
-    weights.save_ttsw(p, {'a/kernel': np.arange(12, dtype=np.float32).reshape(3, 4), 'a/bias': np.ones(4, np.float32)})
-    return p
+from ttsw_cases import corrupt_cases, small_ttsw as _small_ttsw     # shared with tests/test_host_sanitizer.py
 
 
 def test_c_loader_accepts_a_valid_file(lib, tmp_path):
@@ -78,22 +73,8 @@ def test_c_loader_accepts_a_valid_file(lib, tmp_path):
 
 
 def test_c_loader_rejects_corrupt_files(lib, tmp_path):
-    import struct
     good = _small_ttsw(tmp_path).read_bytes()
-    cases = {}
-    cases['missing'] = None
-    cases['bad magic'] = b'XXXX' + good[4:]
-    cases['bad version'] = good[:4] + struct.pack('<I', 9) + good[8:]
-    cases['huge entry count'] = good[:8] + struct.pack('<I', 0xFFFFFFFF) + good[12:]      # would be a 100 GB vector
-    cases['truncated header'] = good[:20]
-    # first entry: name length at 12, name 'a/kernel' (8 bytes), ndim at 24, dims at 28 (2 x int64), off at 44, nbytes at 52
-    cases['negative dim'] = good[:28] + struct.pack('<q', -3) + good[36:]
-    cases['overflowing dims'] = good[:28] + struct.pack('<qq', 1 << 40, 1 << 40) + good[44:]
-    cases['size mismatch'] = good[:52] + struct.pack('<Q', 44) + good[60:]
-    cases['payload outside file'] = good[:44] + struct.pack('<Q', 1 << 40) + good[52:]
-    cases['zero ndim'] = good[:24] + struct.pack('<I', 0) + good[28:]
-    cases['name too long'] = good[:12] + struct.pack('<I', 1 << 30) + good[16:]
-    for what, blob in cases.items():
+    for what, blob in corrupt_cases(good).items():
         p = tmp_path / 'bad.ttsw'
         if blob is None:
             p = tmp_path / 'does_not_exist.ttsw'

@@ -215,6 +215,9 @@ def test_config4_sv2tts_shard_through_rccl_world1(wg_weights, wg_cfg):
 
         audios = synthesize_sharded(tok, synth, speaker=spk)
         assert order['idx'] == sorted(range(4), key=lambda i: (-len(enc[i]), i))      # longest first
+        # the waveforms stayed on the GPU from WaveGlow's output into the RCCL gather: no upload, one download (rank 0's)
+        from text_to_speech_amd import distributed as D
+        assert D.last_transfer == {'scatter_h2d': 2, 'gather_h2d': 0, 'gather_d2h': 1, 'gather_device_resident': True}, D.last_transfer
     finally:
         dist.destroy_process_group()
         eng.close()
@@ -260,6 +263,8 @@ def test_config4_full_batch_of_32_through_rccl_world1(wg_weights, wg_cfg):
         pipe = TTSPipeline(eng)
         kw = dict(max_length=T, deterministic=True, early_stopping=False)
         audios = synthesize_sharded(tok, pipe.shard_fn(**kw), speaker=spk)
+        from text_to_speech_amd import distributed as D
+        assert D.last_transfer['gather_device_resident'] and D.last_transfer['gather_h2d'] == 0 and D.last_transfer['gather_d2h'] == 1
         assert eng.last_decoder_mode == 'graph'                      # 32 rows: above the fused step's 8
         assert len(audios) == N and all(a.shape == (T * 256,) for a in audios)
         order = partition(lens.tolist(), 1)[0]

@@ -328,12 +328,13 @@ def test_runtime_argument_resolution_with_fake_engine():
     assert eng.kw['max_len'] == 25 and eng.kw['prenet_masks'] is None and eng.kw['attn_mask_offset'] == 6
     # noise: drawn on the device from the runtime's (seed, running block offset); an explicit seed restarts at offset 0
     out = rt(np.zeros((2, 3, 80), np.float32), sigma=0.7)
-    assert out.shape == (2, 768) and eng.z is None and eng.seed == 0 and eng.sigma == 0.7
+    from text_to_speech_amd.runtime import MASK_STREAM, NOISE_STREAM
+    assert out.shape == (2, 768) and eng.z is None and eng.seed == 0 ^ NOISE_STREAM and eng.sigma == 0.7
     first = eng.offset
     rt(np.zeros((2, 3, 80), np.float32))
-    assert eng.seed == 0 and eng.offset == first + 2 * 3 * 256 // 4
+    assert eng.seed == 0 ^ NOISE_STREAM and eng.offset == first + 2 * 3 * 256 // 4
     rt(np.zeros((2, 3, 80), np.float32), seed=9)
-    assert (eng.seed, eng.offset) == (9, 0)
+    assert (eng.seed, eng.offset) == (9 ^ NOISE_STREAM, 0) and MASK_STREAM != NOISE_STREAM      # dropout and noise never share blocks
     z = np.ones((1, 96, 8), np.float32)
     rt(np.zeros((3, 80), np.float32), z=z)
     assert eng.z is z and eng.seed is None

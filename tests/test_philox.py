@@ -72,8 +72,9 @@ def test_seeded_waveglow_equals_explicit_noise_from_the_same_stream(gpu_engine, 
         assert float(np.sqrt(np.mean((got - ref) ** 2))) <= 1e-4
     assert np.array_equal(host, dev)
     rt = HipRuntime('unused', engine=gpu_engine, model='waveglow', seed=77)
-    first = rt(mel)                                    # offset 0 of seed 77
-    z0 = philox_ref.normal(B * T * 32 * 8, seed=77, offset=0).reshape(B, T * 32, 8)
+    first = rt(mel)                                    # offset 0 of seed 77's noise stream
+    from text_to_speech_amd.runtime import NOISE_STREAM                    # the runtime's noise key: seed ^ purpose constant
+    z0 = philox_ref.normal(B * T * 32 * 8, seed=77 ^ NOISE_STREAM, offset=0).reshape(B, T * 32, 8)
     assert float(np.sqrt(np.mean((first - waveglow_ref.infer(mel, wg_weights, wg_cfg, z=z0)) ** 2))) <= 1e-4
     second = rt(mel)                                   # the stream has advanced: other noise
     assert not np.array_equal(first, second)

@@ -144,3 +144,52 @@ def test_vocabulary_size_comes_from_the_model_directory(tmp_path):
     (d / 'saving' / 'config_models.json').write_text(json.dumps({'model': {'class_name': 'Tacotron2', 'config': {'vocab_size': 64}}}))
     with pytest.raises(ValueError, match='embedding rows'):
         pretrained.read_model_dir(str(d))
+
+
+def _keras_archive(path, h5_file, compression):
+    """What `model.save('x.keras')` writes (keras.saving.saving_lib): a zip with config.json, metadata.json and model.weights.h5."""
+    import zipfile
+    with zipfile.ZipFile(path, 'w', compression) as z:
+        z.writestr('metadata.json', json.dumps({'keras_version': '3.3.3', 'date_saved': '2024-01-01@00:00:00'}))
+        z.writestr('config.json', json.dumps({'module': 'architectures', 'class_name': 'Tacotron2', 'config': {}}))
+        z.write(h5_file, 'model.weights.h5')
+
+
+@pytest.mark.parametrize('compression', ['stored', 'deflated'])
+def test_keras_archives_are_read_through_their_weights_member(tmp_path, compression):
+    """`.keras` checkpoints (/root/reference/custom_train_objects/checkpoint_manager.py:155,196: the manager saves and restores
+    them beside `.weights.h5`): the archive's model.weights.h5 member -- here the libhdf5-written fixture of
+    tests/golden/make_h5_fixtures.py -- goes through the same importer and yields the same tensors as the bare file."""
+    import zipfile
+    from text_to_speech_amd.weights_import import from_keras_archive, from_keras_file, from_keras_h5
+    h5 = os.path.join(H5, 'keras_tacotron2_walk.weights.h5')
+    arc = tmp_path / 'ckpt-0003.keras'
+    _keras_archive(arc, h5, zipfile.ZIP_STORED if compression == 'stored' else zipfile.ZIP_DEFLATED)
+    want = from_keras_h5(h5, 'tacotron2', TINY['tacotron2'])
+    got = from_keras_file(str(arc), 'tacotron2', TINY['tacotron2'])
+    assert list(got) == list(want) and all(np.array_equal(got[k], want[k]) for k in want)
+    # a model directory whose manager state points at the archive
+    d = tmp_path / 'taco'
+    (d / 'saving').mkdir(parents=True)
+    (d / 'config.json').write_text(json.dumps({'class_name': 'Tacotron2', 'config': {'name': 'taco', 'lang': 'en'}}))
+    shutil.copy(arc, d / 'saving' / 'ckpt-0003.keras')
+    (d / 'saving' / 'checkpoint.json').write_text(json.dumps({'counter': 4, 'loaded': -1,
+                                                              'checkpoints': [{'epoch': 1, 'step': 5, 'counter': 3}]}))
+    out, info = pretrained.convert_model_dir(str(d), cfg=TINY['tacotron2'])
+    assert info['checkpoint'].endswith('ckpt-0003.keras') and out == str(d / 'saving' / 'ckpt-0003.ttsw')
+    conv = load_ttsw(out)
+    assert all(np.array_equal(conv[k], want[k]) for k in want)
+    # refusals: not a zip, no weights member, two of them
+    bad = tmp_path / 'bad.keras'
+    bad.write_bytes(b'not a zip at all')
+    with pytest.raises(ValueError, match='not a zip'):
+        from_keras_archive(str(bad), 'tacotron2', TINY['tacotron2'])
+    with zipfile.ZipFile(bad, 'w') as z:
+        z.writestr('config.json', '{}')
+    with pytest.raises(ValueError, match='model.weights.h5'):
+        from_keras_archive(str(bad), 'tacotron2', TINY['tacotron2'])
+    with zipfile.ZipFile(bad, 'w') as z:
+        z.write(h5, 'model.weights.h5')
+        z.write(h5, 'nested/model.weights.h5')
+    with pytest.raises(ValueError, match='expected one'):
+        from_keras_archive(str(bad), 'tacotron2', TINY['tacotron2'])

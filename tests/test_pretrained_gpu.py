@@ -103,6 +103,33 @@ def test_waveglow_model_directory_with_a_full_size_keras_checkpoint(tmp_path):
     assert err <= WAVE_RMS_TOL
 
 
+def test_model_directory_with_a_keras_archive(tmp_path):
+    """A `.keras` archive as the directory's checkpoint (checkpoint_manager.py:155,196): the full-size WaveGlow weights file
+    written by libhdf5, zipped the way `model.save` does, opened by `pretrained.load_model` and judged by the oracle."""
+    import zipfile
+    from oracle import waveglow_ref
+    from text_to_speech_amd import pretrained
+    from text_to_speech_amd.config import WaveGlowConfig
+    d, save, tensors = _write_checkpoint(tmp_path, 'waveglow_keras', '--full-waveglow')
+    h5 = save / 'ckpt-0000.weights.h5'
+    with zipfile.ZipFile(save / 'ckpt-0000.keras', 'w', zipfile.ZIP_STORED) as z:
+        z.writestr('metadata.json', json.dumps({'keras_version': '3.3.3'}))
+        z.writestr('config.json', json.dumps({'class_name': 'WaveGlow', 'config': {}}))
+        z.write(h5, 'model.weights.h5')
+    os.remove(h5)                                                     # only the archive is left
+    (d / 'config.json').write_text(json.dumps({'class_name': 'WaveGlow', 'config': {'name': d.name}}))
+    (save / 'config_models.json').write_text(json.dumps({'model': {'class_name': 'WaveGlow', 'config': WaveGlowConfig().to_dict()}}))
+    model = pretrained.load_model(str(d), reload=True)
+    assert os.path.exists(save / 'ckpt-0000.ttsw')
+    rng = np.random.default_rng(4)
+    mel = rng.uniform(-11.5, 1.2, (1, 5, 80)).astype(np.float32)
+    z_ = rng.standard_normal((1, 5 * 32, 8)).astype(np.float32)
+    got = model.compiled_infer.engine.waveglow_infer(mel, z=z_)
+    err = float(np.sqrt(np.mean((got - waveglow_ref.infer(mel, tensors, WaveGlowConfig(), z=z_)) ** 2)))
+    print(f'WaveGlow from a .keras archive vs oracle: waveform RMS err {err:.2e}')
+    assert err <= WAVE_RMS_TOL
+
+
 def test_nvidia_layout_state_dicts_through_the_importer(taco_weights, taco_cfg, wg_weights, wg_cfg):
     """NVIDIA torch layouts (weight-normed WaveGlow convs with the fused conditioning layer; Tacotron2 with split LSTM biases):
     export the seeded tensors into that layout, import them back through `weights_import.from_nvidia_*`, load the engine with

@@ -187,6 +187,70 @@ def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_we
         gpu_engine.set_waveglow_form('fft')
 
 
+def test_waveglow_winograd_form_with_four_times_less_end_attenuation(wg_cfg):
+    """The Winograd form where the session weights' 0.05 `end` scaling does not damp it 20x: `end_scale` = 0.2 (signal RMS
+    ~2.6, the largest scale at which a random-weight flow is a well-conditioned map) on 2 x 200 frames
+    = 400 frames per call, which takes the Winograd form by default; the direct form's error is printed beside it.
+    Reference maths: /root/reference/architectures/waveglow_arch.py:105-141.  Absolute tolerance unchanged: 1e-4."""
+    from oracle import waveglow_ref
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.engine import HipEngine
+    w = weights.synth_waveglow(wg_cfg, seed=1234, end_scale=0.2)
+    mel, z = _inputs(2, 200, seed=19)
+    ref = waveglow_ref.infer(mel, w, wg_cfg, z=z, sigma=1.0)
+    eng = HipEngine(0)
+    try:
+        eng.load_state(w)
+        eng.finalize()
+        wino = eng.waveglow_infer(mel, z=z, sigma=1.0)
+        assert eng.last_waveglow_form == 'winograd'               # the default form of a 400-frame fp32 call
+        eng.set_waveglow_form('direct')
+        direct = eng.waveglow_infer(mel, z=z, sigma=1.0)
+        assert eng.last_waveglow_form == 'direct'
+    finally:
+        eng.close()
+    e_w, e_d = rms(wino - ref), rms(direct - ref)
+    print(f'end_scale=0.2, 2 x 200 frames: winograd rms_err={e_w:.3e}  direct rms_err={e_d:.3e}  ref_rms={rms(ref):.3f} '
+          f'max|ref|={np.abs(ref).max():.1f}  winograd vs direct {rms(wino - direct):.3e}')
+    assert rms(ref) > 1.5 and e_w <= RMS_TOL and e_d <= RMS_TOL
+
+
+# relative RMS error bound of one WN layer's gated activations (|acts| < 1, RMS ~0.3): fp32 rounding of a K = 1856 dot
+# product is ~1e-6 relative; F(4,3)'s transform constants cost a factor ~3 (csrc/wn_wino.hip).  Measured: see the printout.
+ACTS_REL_TOL = 2e-5
+
+
+def test_wn_layer_activations_against_the_oracle_in_both_forms(gpu_engine, wg_weights, wg_cfg):
+    """Layer-level parity, before the res/skip and `end` convolutions attenuate anything: the gated activations
+    tanh(.) * sigmoid(.) of one WN layer per Winograd group kind -- dilation 4 (four phases of a frame), 16 (two phases x two
+    frames), 64 (four frames of a phase) -- of the first flow that runs (flow 11), against `oracle/waveglow_ref.wn_block`
+    intermediates on the same x / mel, in the Winograd and in the direct form.  2 x 200 frames: the Winograd form's domain.
+    Reference: /root/reference/architectures/waveglow_arch.py:19-24,105-127."""
+    from oracle import waveglow_ref
+    mel, z = _inputs(2, 200, seed=23)
+    w = {k: v for k, v in wg_weights.items() if k.startswith('waveglow/')}
+    spect = waveglow_ref.regroup(waveglow_ref.upsample(mel, w['waveglow/upsample/kernel'], w['waveglow/upsample/bias'],
+                                                       wg_cfg.upsample_stride), wg_cfg.n_group)
+    n_half = wg_cfg.n_remaining_channels // 2
+    ref_acts = []
+    waveglow_ref.wn_block(z[:, :, :n_half], spect, w, 'waveglow/block-11', wg_cfg.n_layers, wg_cfg.n_channels,
+                          collect=ref_acts, stop_after=6)
+    try:
+        for layer in (2, 4, 6):
+            ref = ref_acts[layer]
+            errs = {}
+            for form in ('winograd', 'direct'):
+                gpu_engine.set_waveglow_form(form)
+                acts = gpu_engine.waveglow_probe_acts(mel, z=z, flow=11, layer=layer)
+                assert gpu_engine.last_waveglow_form == form and acts.shape == ref.shape
+                errs[form] = rms(acts - ref) / rms(ref)
+            print(f'WN layer {layer} (dilation {1 << layer}): acts rel. RMS error winograd {errs["winograd"]:.3e}, '
+                  f'direct {errs["direct"]:.3e} (acts RMS {rms(ref):.3f})')
+            assert errs['winograd'] <= ACTS_REL_TOL and errs['direct'] <= ACTS_REL_TOL
+    finally:
+        gpu_engine.set_waveglow_form('winograd')
+
+
 def test_waveglow_config2_rows_equal_batch1_runs(gpu_engine):
     """Full BASELINE.json config 2 (8 x 800 frames, 256-row tiles, Winograd form) against batch-1 runs of single rows in both
     forms (Winograd on 256-row tiles, direct on 128-row tiles): a size-independent property (utterances are independent) that

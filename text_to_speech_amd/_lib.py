@@ -15,7 +15,7 @@ LIB_NAME = 'libtts_hip.so'
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class HipLibraryError(RuntimeError):
@@ -46,6 +46,7 @@ SIGNATURES = {
     'tts_hip_last_decoder_mode': (c_int, [c_void_p]),
     'tts_hip_set_waveglow_form': (c_int, [c_void_p, c_int]),
     'tts_hip_last_waveglow_form': (c_int, [c_void_p]),
+    'tts_hip_waveglow_probe_acts': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_int]),
     'tts_hip_mel_stft': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
     'tts_hip_waveglow_infer_async': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     'tts_hip_mel_stft_async': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -16,7 +16,7 @@ for src in engine waveglow wn_wino tacotron2 taco_persist taco_fused mel_stft; d
   obj="$bdir/$src.o"
   objs+=("$obj")
   if [[ ! -f "$obj" || "$here/$src.hip" -nt "$obj" || "$here/gemm_f32.h" -nt "$obj" || "$here/engine.h" -nt "$obj" \
-        || "$here/taco_persist.h" -nt "$obj" || "$here/xch_util.h" -nt "$obj" || "$here/taco_fused.h" -nt "$obj" \
+        || "$here/taco_persist.h" -nt "$obj" || "$here/ttsw_host.h" -nt "$obj" || "$here/xch_util.h" -nt "$obj" || "$here/taco_fused.h" -nt "$obj" \
         || "$here/../../include/tts_hip.h" -nt "$obj" ]]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$here/$src.hip" -o "$obj" &
     pids+=($!)

@@ -11,15 +11,7 @@
 
 #include "../../include/tts_hip.h"
 
-struct HostTensor {
-    std::vector<int64_t> dims;
-    std::vector<float> data;
-    size_t numel() const {
-        size_t n = 1;
-        for (auto d : dims) n *= (size_t)d;
-        return n;
-    }
-};
+#include "ttsw_host.h"      // HostTensor + the TTSW parser (host-only code, also built under ASan / UBSan)
 
 // Growable device buffer (workspace).  Never shrinks; reallocated only when a larger request arrives.
 struct DevBuf {
@@ -54,7 +46,8 @@ struct WgLayerDev {
     _Float16* cond_Bt_x3 = nullptr;
     _Float16* rs_Bt_x3 = nullptr;
     float* wino_G = nullptr;    // Winograd form (wn_wino.hip; built on first use): [6][1024][512] tap combinations and the
-    float* wino_V = nullptr;    //   conditioning planes of the layer's group kind ([8 or 32][6][1024][224] / [16][4][1024][320])
+    float* wino_V = nullptr;    //   conditioning planes of the phase / mixed groups ([8][6][1024][224] / [16][4][1024][320])
+    float* wino_Vf = nullptr;   //   three-pass form only: column-selected copies for the frame groups [32][6][1024][224]
     float* rs_Bt = nullptr;     // [512][512] residual half of res_skip (layers 0..6)
     float* rs_bias = nullptr;   // [512]
     int rs_n = 0;
@@ -76,7 +69,10 @@ struct WaveGlowDev {
     bool f16_ready = false, x3_ready = false;
     DevBuf x16, acts16, a0p16, mel16;        // fp16 path: shadow of x, activations, first-layer operand, mel
     int form_mode = 1, last_form = -1;       // tts_hip_set_waveglow_form / tts_hip_last_waveglow_form
+    int probe_flow = -1, probe_layer = -1;   // tts_hip_waveglow_probe_acts (test hook): stop after this layer and copy
+    float* probe_out = nullptr;              //   its gated activations to this device buffer [B][T * 32][512]
     bool wino_ready = false;                 // Winograd form of the fp32 in-layer GEMM (wn_wino.hip)
+    bool wino_legacy_ready = false;          //   ... and the three-pass form's extra weight copies
     DevBuf wino_U, wino_P, wino_mel;         // transformed inputs [4][M/2][512], products [4][M/2][1024], mel planes
 };
 
@@ -205,8 +201,8 @@ void tacotron2_graphs_clear(tts_hip_engine* e);
     } while (0)
 
 // Winograd form of the WN in-layer GEMM (wn_wino.hip)
-int waveglow_build_wino(tts_hip_engine* e);
-int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T);
+int waveglow_build_wino(tts_hip_engine* e, bool legacy_frames);
+int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T, bool three_pass);
 int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const float* x, float* acts_i, int PR, int BT, int T);
 // timing helpers (engine.hip)
 void timing_begin(tts_hip_engine* e, int kind);

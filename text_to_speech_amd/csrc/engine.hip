@@ -1,5 +1,6 @@
 // engine.hip -- C ABI entry points: handle lifetime, weight intake, host/device staging, timing hooks.
 #include "engine.h"
+#include "ttsw_host.h"
 
 #include <cstdarg>
 #include <cstring>
@@ -22,7 +23,11 @@ const HostTensor* find_tensor(const tts_hip_engine* e, const std::string& name) 
 
 int dev_alloc(tts_hip_engine* e, size_t n_floats, float** dst, std::vector<void*>& allocs, bool zero) {
     void* p = nullptr;
-    HIPCHK(e, hipMalloc(&p, n_floats * sizeof(float)));
+    if (hipError_t err = hipMalloc(&p, n_floats * sizeof(float)); err != hipSuccess) {
+        if (err == hipErrorOutOfMemory) (void)hipGetLastError();
+        return set_err(e, err == hipErrorOutOfMemory ? TTS_HIP_ENOMEM : TTS_HIP_EHIP, "hipMalloc(%zu bytes) -> %s",
+                       n_floats * sizeof(float), hipGetErrorString(err));
+    }
     allocs.push_back(p);
     if (zero) HIPCHK(e, hipMemsetAsync(p, 0, n_floats * sizeof(float), e->stream));
     *dst = (float*)p;
@@ -134,7 +139,7 @@ int philox_fill(tts_hip_engine* e, float* out, long long n, uint64_t seed, uint6
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 9; }
+int tts_hip_abi_version(void) { return 10; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -174,18 +179,6 @@ int tts_hip_destroy(tts_hip_engine* e) {
 
 const char* tts_hip_last_error(const tts_hip_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
-// numel of `dims` if every dim is positive and the product stays below kMaxTensorElems (2^34 floats = 64 GiB); 0 otherwise
-static size_t checked_numel(const std::vector<int64_t>& dims) {
-    constexpr uint64_t kMaxTensorElems = 1ull << 34;
-    uint64_t n = 1;
-    for (int64_t d : dims) {
-        if (d <= 0 || (uint64_t)d > kMaxTensorElems) return 0;
-        n *= (uint64_t)d;
-        if (n > kMaxTensorElems) return 0;
-    }
-    return (size_t)n;
-}
-
 int tts_hip_set_tensor(tts_hip_engine* e, const char* name, const float* data, const int64_t* dims, int ndim) {
     if (!e || !name || !data || !dims || ndim <= 0 || ndim > 8) return set_err(e, TTS_HIP_EINVAL, "set_tensor: bad argument");
     try {
@@ -198,67 +191,6 @@ int tts_hip_set_tensor(tts_hip_engine* e, const char* name, const float* data, c
     } catch (const std::exception& ex) {                       // bad_alloc / length_error must not cross the C boundary
         return set_err(e, TTS_HIP_ENOMEM, "set_tensor(%s): %s", name, ex.what());
     }
-    return TTS_HIP_OK;
-}
-
-// Parses a TTSW file into `out` (may be null: validation only).  Nothing in the file is trusted: the entry count, name
-// lengths, dims and payload ranges are all checked against the file size before anything is allocated from them.
-static int parse_ttsw(const char* path, std::map<std::string, HostTensor>* out, std::string* err) {
-    FILE* f = fopen(path, "rb");
-    if (!f) {
-        *err = std::string("cannot open ") + path;
-        return TTS_HIP_EIO;
-    }
-    auto fail = [&](const char* what) {
-        fclose(f);
-        *err = std::string(path) + ": " + what;
-        return TTS_HIP_EIO;
-    };
-    if (fseek(f, 0, SEEK_END) != 0) return fail("cannot seek");
-    const long long fsize = ftell(f);
-    if (fsize < 12 || fseek(f, 0, SEEK_SET) != 0) return fail("not a TTSW file");
-    char magic[4];
-    uint32_t ver = 0, n = 0;
-    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "TTSW", 4) != 0) return fail("not a TTSW file");
-    if (fread(&ver, 4, 1, f) != 1 || fread(&n, 4, 1, f) != 1 || ver != 1) return fail("unsupported version");
-    // an entry header is at least 4 + 1 + 4 + 8 + 8 + 8 = 33 bytes
-    if ((unsigned long long)n * 33ull > (unsigned long long)fsize) return fail("entry count exceeds file size");
-    struct Ent {
-        std::string name;
-        std::vector<int64_t> dims;
-        uint64_t off, nbytes;
-    };
-    try {
-        std::vector<Ent> ents(n);
-        for (auto& en : ents) {
-            uint32_t ln = 0, nd = 0;
-            if (fread(&ln, 4, 1, f) != 1 || ln == 0 || ln > 4096) return fail("bad name length");
-            en.name.resize(ln);
-            if (fread(&en.name[0], 1, ln, f) != ln) return fail("truncated header");
-            if (fread(&nd, 4, 1, f) != 1 || nd == 0 || nd > 8) return fail("bad ndim");
-            en.dims.resize(nd);
-            if (fread(en.dims.data(), 8, nd, f) != nd) return fail("truncated header");
-            if (fread(&en.off, 8, 1, f) != 1 || fread(&en.nbytes, 8, 1, f) != 1) return fail("truncated header");
-            const size_t numel = checked_numel(en.dims);
-            if (!numel) return fail("non-positive or oversized dim");
-            if ((uint64_t)numel * sizeof(float) != en.nbytes) return fail("size mismatch");
-            if (en.off > (uint64_t)fsize || en.nbytes > (uint64_t)fsize - en.off) return fail("payload outside the file");
-        }
-        for (auto& en : ents) {
-            if (!out) continue;
-            HostTensor t;
-            t.dims = en.dims;
-            t.data.resize(en.nbytes / sizeof(float));
-            if (fseek(f, (long)en.off, SEEK_SET) != 0 || fread(t.data.data(), 1, en.nbytes, f) != en.nbytes)
-                return fail("truncated payload");
-            (*out)[en.name] = std::move(t);
-        }
-    } catch (const std::exception& ex) {
-        fclose(f);
-        *err = std::string(path) + ": " + ex.what();
-        return TTS_HIP_ENOMEM;
-    }
-    fclose(f);
     return TTS_HIP_OK;
 }
 
@@ -381,6 +313,47 @@ int tts_hip_waveglow_infer_f16x3(tts_hip_engine* e, const float* mel, int B, int
     return waveglow_infer_impl(e, mel, B, T, z, sigma, audio, mem, 2);
 }
 
+// Test hook: the gated activations of one WN layer (before the res/skip and `end` convolutions), natural position order.
+int tts_hip_waveglow_probe_acts(tts_hip_engine* e, const float* mel, int B, int T, const float* z, float sigma, int flow,
+                                int layer, float* acts, int mem) {
+    if (!e) return TTS_HIP_EINVAL;
+    if (!e->wg.ready) return set_err(e, TTS_HIP_ENOTREADY, "waveglow weights not finalized");
+    if (!mel || !acts || B <= 0 || T <= 0 || flow < 0 || flow > 11 || layer < 0 || layer > 7 || (long long)B * T > 31744)
+        return set_err(e, TTS_HIP_EINVAL, "waveglow_probe_acts: bad argument");
+    if (mem != TTS_HIP_MEM_HOST && mem != TTS_HIP_MEM_DEVICE) return set_err(e, TTS_HIP_EINVAL, "waveglow_probe_acts: bad mem kind %d", mem);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t n_mel = (size_t)B * T * 80, n_z = (size_t)B * T * 32 * 8, n_acts = (size_t)B * T * 32 * 512;
+    const float* d_mel = mel;
+    const float* d_z = z;
+    DevBuf tmp;
+    if (mem == TTS_HIP_MEM_HOST) {
+        HIPCHK(e, e->wg.io_mel.ensure(n_mel * 4));
+        HIPCHK(e, hipMemcpyAsync(e->wg.io_mel.p, mel, n_mel * 4, hipMemcpyHostToDevice, e->stream));
+        d_mel = e->wg.io_mel.f();
+        if (z) {
+            HIPCHK(e, e->wg.io_z.ensure(n_z * 4));
+            HIPCHK(e, hipMemcpyAsync(e->wg.io_z.p, z, n_z * 4, hipMemcpyHostToDevice, e->stream));
+            d_z = e->wg.io_z.f();
+        }
+        HIPCHK(e, tmp.ensure(n_acts * 4));
+    }
+    HIPCHK(e, e->wg.io_out.ensure((size_t)B * T * 256 * 4));      // the run's audio argument (not reached before the stop)
+    e->wg.probe_flow = flow;
+    e->wg.probe_layer = layer;
+    e->wg.probe_out = mem == TTS_HIP_MEM_HOST ? tmp.f() : acts;
+    int rc = waveglow_run(e, d_mel, B, T, d_z, sigma, e->wg.io_out.f(), 0);
+    e->wg.probe_out = nullptr;
+    e->wg.probe_flow = e->wg.probe_layer = -1;
+    hipError_t herr = hipSuccess;
+    if (!rc && mem == TTS_HIP_MEM_HOST) herr = hipMemcpyAsync(acts, tmp.p, n_acts * 4, hipMemcpyDeviceToHost, e->stream);
+    const hipError_t serr = hipStreamSynchronize(e->stream);
+    tmp.release();
+    if (rc) return rc;
+    HIPCHK(e, herr);
+    HIPCHK(e, serr);
+    return TTS_HIP_OK;
+}
+
 int tts_hip_random_fill(tts_hip_engine* e, int kind, uint64_t seed, uint64_t offset, float* out, int64_t n, void* stream) {
     if (!e) return TTS_HIP_EINVAL;
     if (!out || n < 0 || (kind != TTS_HIP_RANDOM_NORMAL && kind != TTS_HIP_RANDOM_PRENET_MASK))
@@ -498,7 +471,8 @@ int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode) {
 int tts_hip_last_decoder_mode(const tts_hip_engine* e) { return e ? e->taco.last_path : -1; }
 
 int tts_hip_set_waveglow_form(tts_hip_engine* e, int form) {
-    if (!e || form < 0 || form > 1) return set_err(e, TTS_HIP_EINVAL, "set_waveglow_form: form must be 0 (direct) or 1 (Winograd when the call shape allows it)");
+    if (!e || form < 0 || form > 7)
+        return set_err(e, TTS_HIP_EINVAL, "set_waveglow_form: form must be 0 (direct), 1 (Winograd when the call shape allows it) or a measurement form 2 .. 7");
     e->wg.form_mode = form;
     return TTS_HIP_OK;
 }

@@ -144,6 +144,18 @@ __global__ void mel_window_kernel(const float* __restrict__ mel, _Float16* __res
     put_split(dst, lo, i, t - q >= 0 ? mel[(long long)(f - q) * 80 + j] : 0.f);
 }
 
+// test hook (tts_hip_waveglow_probe_acts): phase-major rows m' = p * PR + b * T + t of one layer's gated activations ->
+// natural order [B][T * 32][512] (position l = 32 t + p)
+__global__ void probe_acts_kernel(const float* __restrict__ acts, float* __restrict__ out, int PR, int BT, int T) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one float4 of one position
+    if (idx >= (long long)BT * NPH * (C / 4)) return;
+    const int c = (int)(idx % (C / 4)) * 4;
+    const long long pos = idx / (C / 4);               // b * T * 32 + l
+    const int p = (int)(pos % NPH);
+    const long long f = pos / NPH;                     // b * T + t
+    *reinterpret_cast<f32x4*>(out + pos * C + c) = *reinterpret_cast<const f32x4*>(acts + ((long long)p * PR + f) * C + c);
+}
+
 // audio[m'][0..3] = sigma * z[natural m][0..3]  (z null => zeros); m' = p * PR + f  <->  m = f * 32 + p
 __global__ void init_audio_kernel(const float* __restrict__ z, float sigma, float* __restrict__ audio, int PR, int BT) {
     const long long mp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -393,6 +405,7 @@ void waveglow_free(tts_hip_engine* e) {
     e->wg.wino_P.release();
     e->wg.wino_mel.release();
     e->wg.wino_ready = false;
+    e->wg.wino_legacy_ready = false;
     e->wg.f16_ready = false;
     e->wg.x3_ready = false;
     e->wg.io_mel.release();
@@ -741,7 +754,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     // It pays from about 350 frames per call (one sentence, measured: 400 frames 44.4 -> 38.2 ms, 513: 61.2 -> 55.6, 800: 84.7 ->
     // 67.2; 300 frames break even, 100 frames lose 40 % to its two HBM-bound passes and six-slice launches); a call of that
     // size whose rows would pad better on 64-row tiles takes the 128-row tiles when that is clearly less work
-    const bool wino_size = precision == 0 && wg.form_mode == 1 && BT >= 384;
+    const bool wino_size = precision == 0 && wg.form_mode >= 1 && BT >= 384;
     if (wino_size && row64 && (double)pr128 * 1120.0 * 1.35 < (double)pr64 * 1856.0) {
         row64 = false;
         tile128 = pr128 * 1.05 < pr256;
@@ -768,12 +781,21 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     // fp32 path, 128- / 256-row tiles: layers 1 .. 7 of a flow run in their Winograd form (wn_wino.hip)
     bool wino = wino_size && !row64;                                      // (PR is a multiple of 128)
     if (wino) {
-        // its operands (6.4 GB of weight planes on first use, 2.6 GB of workspace at config 2) are extra: when the device
-        // cannot hold them this handle keeps the direct form from now on instead of failing the call
-        int rc = waveglow_build_wino(e);
-        if (!rc) rc = waveglow_wino_begin(e, d_mel, PR, BT, T);
+        // its operands (3.6 GB of weight planes on first use, 0.7 GB of workspace at config 2) are extra: when the device cannot
+        // hold them -- and only then: any other error is the call's error -- this handle keeps the direct form from now on
+        const bool three_pass = wg.form_mode == 2;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
+        const size_t need = wg.wino_ready && (!three_pass || wg.wino_legacy_ready) ? 0 : (size_t)(three_pass ? 11 : 4) << 30;
+        int rc = free_b < need ? TTS_HIP_ENOMEM : waveglow_build_wino(e, three_pass);
+        bool oom = rc == TTS_HIP_ENOMEM;
+        if (!rc) {
+            rc = waveglow_wino_begin(e, d_mel, PR, BT, T, three_pass);
+            oom = rc == TTS_HIP_ENOMEM;
+        }
+        if (rc && !oom) return rc;
         if (rc) {
-            (void)hipGetLastError();
+            (void)hipGetLastError();                                      // (clears the sticky out-of-memory status)
             wg.form_mode = 0;
             wino = false;
         }
@@ -848,6 +870,13 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
                     if (i == 0) HIPCHK(e, row64 ? gemm_wn_in0_r64(g, st) : tile64 ? gemm_wn_in0_64(g, st) : tile128 ? gemm_wn_in0_128(g, st) : gemm_wn_in0(g, st));
                     else HIPCHK(e, row64 ? gemm_wn_in_r64(g, st) : tile64 ? gemm_wn_in_64(g, st) : tile128 ? gemm_wn_in_128(g, st) : gemm_wn_in(g, st));
                     timing_end(e);
+                }
+                if (wg.probe_out && wg.probe_flow == k && wg.probe_layer == i) {        // test hook: stop here
+                    const long long n4 = (long long)BT * NPH * (C / 4);
+                    hipLaunchKernelGGL(probe_acts_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, acts_i,
+                                       wg.probe_out, PR, BT, T);
+                    HIPCHK(e, hipGetLastError());
+                    return TTS_HIP_OK;
                 }
                 if (i < 7) {             // residual: x += acts_i @ W_res + b_res   (skip half folded into wn_end_fold)
                     GemmArgs r{};

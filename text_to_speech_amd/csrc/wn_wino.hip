@@ -363,45 +363,315 @@ __global__ void wino4_combine_kernel(const float* __restrict__ P, const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fused form of the GEMM + combine passes.  One block owns BM group rows x BN pre-activation columns of ALL SIX products: its
+// K loop walks product after product (K = 512 + the product's conditioning chunks) through one LDS-DMA pipeline, each product
+// into its own accumulator set (a wave holds 32 rows x 64 columns x 6 products = 192 accumulator registers), and the epilogue
+// applies the output transform, bias and gate in registers and stores the four output row sets of `acts` -- no P planes
+// (1.26 GB written and read per layer at config 2), no combine launch.  Same products in the same k order as the three-pass
+// form, so the two agree to the last bit of the fp32 sums (the output transform is written identically).
+// The conditioning chunks of a product are a chunk range of its mel plane against one or two chunk ranges of the weight rows:
+// for the frame groups (dilations >= 32) the products' weights are column selections of cond_Bt itself -- A = chunks 0 .. 6,
+// B = 7 .. 12, C = 13 .. 19 of its 320 columns -- so no per-product copies exist, and the all-zero padding chunk of the
+// 208-column products is skipped (45 K steps instead of 46 for four of the six products).
+struct WinoFusedArgs {
+    const float* U;   long long uplane;                       // transformed inputs [6][Mq][512]
+    const float* G;   long long gplane;                       // tap combinations [6][1024][512]
+    const float* mel; long long mplane; int ldm;              // conditioning operand planes (row stride ldm); plane p - pofs
+    const float* V;   long long vplane, strideVp; int ldv;    // conditioning weights: V + phase * strideVp + (p - pofs) * vplane
+    int pofs;
+    unsigned long long cfg_lo, cfg_hi; // product p's conditioning chunks (16 columns each), 16 bits per product (p < 4: cfg_lo):
+                                       // n1 | b1 << 5 | n2 << 9 | b2 << 12 -- operand chunks 0 .. n1 + n2 - 1 against weight chunks
+                                       // b1 .. b1 + n1 - 1, then b2 .. b2 + n2 - 1
+    const float* bias;                 // [1024] (gate-permuted like the weight rows)
+    float* acts;                       // [32 PR][512]
+    int Mq, phase_rows;                // group rows; group rows per (group) phase block
+    int kind;                          // 0 phase groups (d <= 8), 1 frame groups (d >= 32), 2 mixed groups (d = 16)
+    int d, PR, BT, T;
+};
+
+template <int WR, int WC, int NBUF, int OCC>
+__global__ __launch_bounds__(WR * WC * 64, OCC) void wino4_fused_kernel(const WinoFusedArgs g) {
+    constexpr int NW = WR * WC, BM = WR * 32, BN = WC * 64;
+    constexpr int NPA = BM / 16, NPB = BN / 16, PPW = (NPA + NPB) / NW;     // 16-row DMA pieces: A side, B side, per wave
+    static_assert((NPA + NPB) % NW == 0, "the pieces of a tile divide among the waves");
+    constexpr int STAGE = (BM + BN) * 16;                                   // floats per LDS buffer: [A rows | B rows] x 16 k
+    static_assert(NBUF * STAGE >= NW * 32 * 36, "the epilogue's transpose patches fit the pipeline buffers");
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order (as gemm_f32_kernel): the numNt column blocks of an M tile run back to back on one XCD
+    constexpr int numNt = 2 * C / BN;
+    const int numMt = g.Mq / BM;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int mt = (slot / numNt) * 8 + xcd, nt = slot % numNt;
+    if (mt >= numMt) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int ph = m0 / g.phase_rows, fr0 = m0 - ph * g.phase_rows;        // block-uniform (group) phase, first row inside it
+
+    f32x16 acc[6][2];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][h][r] = 0.f;
+
+    // ---- tile stream.  Piece q of a tile = 16 rows x 64 B: q < NPA operand rows, else weight rows; lane l of a piece fetches
+    // chunk (l & 3) ^ ((l >> 4) & 3) of row l >> 2 and lands at byte 16 l of the piece (XOR swizzle through the source address)
+    const int prow = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned vo0[PPW], vo1[PPW];                                            // per-lane byte offsets: K = 512 part / conditioning part
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const bool isA = q < NPA;
+        const int row = (isA ? q : q - NPA) * 16 + prow;
+        vo0[i] = (unsigned)((row * C + chunk * 4) * 4);
+        vo1[i] = (unsigned)((row * (isA ? g.ldm : g.ldv) + chunk * 4) * 4);
+    }
+    // product p's conditioning chunks: a 16-bit field of two 64-bit words, extracted with shifts (pure scalar ALU: a select
+    // chain over six kernel arguments is turned by hipcc into a scalar LOAD from a selected address inside the K loop -- or,
+    // with the words held in variables, into a table of pointers in scratch)
+    const unsigned long long cfg_lo = g.cfg_lo, cfg_hi = g.cfg_hi;
+    auto cfg_of = [&](int p) -> unsigned {
+        return (unsigned)((p < 4 ? cfg_lo >> (16 * (p & 3)) : cfg_hi >> (16 * (p & 3))) & 0xffffull);
+    };
+    int lp = 0, lseg = 0, lkc = 0;                                          // (product, part, chunk) of the next tile to request
+    unsigned lcfg = cfg_of(0);
+    const float *abase = nullptr, *bbase = nullptr;
+    auto seg_setup = [&]() {
+        if (lseg == 0) {
+            abase = g.U + lp * g.uplane + (long long)m0 * C;
+            bbase = g.G + lp * g.gplane + (long long)n0 * C;
+        } else {
+            abase = g.mel + (lp - g.pofs) * g.mplane + (long long)fr0 * g.ldm;
+            bbase = g.V + ph * g.strideVp + (lp - g.pofs) * g.vplane + (long long)n0 * g.ldv;
+        }
+    };
+    // The tile stream in two parts, as in gemm_f32_kernel's rotated loop: `prepare` does the (scalar) address math of the next
+    // tile, `issue_piece` requests one 16-row piece of it.
+    unsigned vo[PPW], ko[PPW];                                              // per-lane offsets / scalar K offsets of the prepared tile
+    const float* pb[PPW];                                                   // (wave-uniform) descriptor bases of its pieces
+    auto prepare = [&]() {
+        const bool live = lp < 6;                                           // past the last tile the pieces fetch nothing
+        const int n1 = lcfg & 31, b1 = (lcfg >> 5) & 15, n2 = (lcfg >> 9) & 7, b2 = lcfg >> 12;
+        const unsigned ka = (unsigned)lkc * 64u;
+        const unsigned kb = lseg == 0 ? ka : (unsigned)(lkc < n1 ? b1 + lkc : b2 + lkc - n1) * 64u;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const bool isA = wave * PPW + i < NPA;                          // wave-uniform
+            pb[i] = isA ? abase : bbase;
+            ko[i] = isA ? ka : kb;
+            vo[i] = live ? (lseg == 0 ? vo0[i] : vo1[i]) : OOB;
+        }
+        if (live && ++lkc == (lseg == 0 ? C / 16 : n1 + n2)) {
+            lkc = 0;
+            if (lseg == 0 && n1 + n2 > 0) {
+                lseg = 1;
+            } else {
+                lseg = 0;
+                lcfg = cfg_of(++lp);
+            }
+            seg_setup();
+        }
+    };
+    auto issue_piece = [&](int i, int buf) {
+        // (by-value copies: with an element of a local array as the builtin's operand hipcc's HOST pass silently emits no stub
+        //  for the kernel -- undefined symbol when the library is loaded)
+        const unsigned voff = vo[i], koff = ko[i];
+        const float* base = pb[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc_uniform(base), (lds_ptr_t)(smem + buf * STAGE + (wave * PPW + i) * 256), 16,
+                                                 voff, koff, 0, 0);
+    };
+    const int xr = (li >> 2) & 3;
+    struct Frag {
+        f32x4 a, b0, b1;
+    };
+    auto read_frag = [&](int buf, int k8, Frag& f) {                        // the K = 8 half k8 of a tile: one A and two B fragments
+        const int koff = ((2 * k8 + lh) ^ xr) * 4;
+        const float* a = smem + buf * STAGE + (wr * 32 + li) * 16 + koff;
+        const float* b = smem + buf * STAGE + BM * 16 + (wc * 64 + li) * 16 + koff;
+        f.a = *reinterpret_cast<const f32x4*>(a);
+        f.b0 = *reinterpret_cast<const f32x4*>(b);
+        f.b1 = *reinterpret_cast<const f32x4*>(b + 32 * 16);
+    };
+
+    // K loop, rotated by half a step (gemm_f32_kernel: the plain loop left the matrix pipe idle after every barrier while all
+    // waves issued their DMA pieces and waited for their operand reads: 71 % of peak).  Step t = [reads of tile t's second half |
+    // MFMAs of its first half | wait for tile t + 1, barrier | reads of tile t + 1's first half | MFMAs of the second half with
+    // the pieces of tile t + NBUF requested one per MFMA pair into tile t's buffer -- every wave holds tile t in registers].
+    seg_setup();
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b) {
+        prepare();
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) issue_piece(i, b);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NBUF - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+    read_frag(0, 0, f0);
+    int buf = 0;
+    static_for<6>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        const unsigned c = cfg_of(P);
+        const int nsteps = C / 16 + (int)(c & 31) + (int)((c >> 9) & 7);
+        for (int s = 0; s < nsteps; ++s) {
+            read_frag(buf, 1, f1);
+            prepare();                                                      // tile t + NBUF (address math only)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a[kk], f0.b0[kk], acc[P][0], 0, 0, 0);
+                acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a[kk], f0.b1[kk], acc[P][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                              // (keeps the MFMAs above the wait)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW * (NBUF - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int bufn = buf == NBUF - 1 ? 0 : buf + 1;
+            read_frag(bufn, 0, f0);                                         // (past the last tile: zeros nothing uses)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.a[kk], f1.b0[kk], acc[P][0], 0, 0, 0);
+                acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.a[kk], f1.b1[kk], acc[P][1], 0, 0, 0);
+                if (kk < PPW) {
+                    issue_piece(kk, buf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            static_assert(PPW <= 4, "one DMA piece per MFMA pair of the second half");
+            buf = bufn;
+        }
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the fetch-nothing pieces of the last steps
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: output transform + bias + gate in registers (the arithmetic of wino4_combine_kernel), each gated 32 x 32
+    // tile transposed through a wave-private LDS patch so that a lane stores 16 bytes of one acts row
+    float* patch = smem + wave * (32 * 36);
+    const int er = lane >> 3, ec4 = (lane & 7) * 4;
+    const float bt = g.bias[n0 + wc * 64 + li], bs = g.bias[n0 + wc * 64 + 32 + li];
+    const int ch0 = ((n0 + wc * 64) >> 6) * 32 + ec4;
+    const int sfr = g.d / NPH;
+    auto out_row = [&](int lr, int j) -> long long {                        // acts row of output j of local group row lr (-1: none)
+        const int gl = fr0 + lr;                                            // group row inside the (group) phase block
+        if (g.kind == 0) return (long long)(group_phase0(ph, g.d) + j * g.d) * g.PR + gl;
+        int b, t0;
+        if (g.kind == 1) {
+            if (!frame_group(gl, sfr, g.BT, g.T, b, t0) || t0 + j * sfr >= g.T) return -1;
+            return (long long)ph * g.PR + (long long)b * g.T + t0 + j * sfr;
+        }
+        if (!mixed_group(gl, g.BT, g.T, b, t0) || t0 + (j >> 1) >= g.T) return -1;
+        return (long long)(ph + 16 * (j & 1)) * g.PR + (long long)b * g.T + t0 + (j >> 1);
+    };
+    static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float tv, sv;
+            if constexpr (j == 0) {
+                tv = acc[0][0][r] + acc[1][0][r] + acc[2][0][r] + acc[3][0][r] + acc[4][0][r] + bt;
+                sv = acc[0][1][r] + acc[1][1][r] + acc[2][1][r] + acc[3][1][r] + acc[4][1][r] + bs;
+            } else if constexpr (j == 1) {
+                tv = acc[1][0][r] - acc[2][0][r] + 2.f * (acc[3][0][r] - acc[4][0][r]) + bt;
+                sv = acc[1][1][r] - acc[2][1][r] + 2.f * (acc[3][1][r] - acc[4][1][r]) + bs;
+            } else if constexpr (j == 2) {
+                tv = acc[1][0][r] + acc[2][0][r] + 4.f * (acc[3][0][r] + acc[4][0][r]) + bt;
+                sv = acc[1][1][r] + acc[2][1][r] + 4.f * (acc[3][1][r] + acc[4][1][r]) + bs;
+            } else {
+                tv = acc[1][0][r] - acc[2][0][r] + 8.f * (acc[3][0][r] - acc[4][0][r]) + acc[5][0][r] + bt;
+                sv = acc[1][1][r] - acc[2][1][r] + 8.f * (acc[3][1][r] - acc[4][1][r]) + acc[5][1][r] + bs;
+            }
+            patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = gate_tanh_sigmoid(tv, sv);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // wave-private patch: no barrier needed
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(patch + (er + 8 * qq) * 36 + ec4);
+            const long long row = out_row(wr * 32 + er + 8 * qq, j);
+            if (row >= 0) *reinterpret_cast<f32x4*>(g.acts + row * C + ch0) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // patch reads done before the next output overwrites it
+    });
+}
+
+template <int WR, int WC, int NBUF, int OCC>
+hipError_t launch_wino_fused(const WinoFusedArgs& a, hipStream_t st) {
+    constexpr int BM = WR * 32, BN = WC * 64;
+    const size_t lds = (size_t)NBUF * (BM + BN) * 16 * sizeof(float);
+    if (a.Mq % BM != 0 || a.phase_rows % BM != 0 || a.Mq % a.phase_rows != 0) return hipErrorInvalidValue;
+    auto kern = wino4_fused_kernel<WR, WC, NBUF, OCC>;
+    static PerDeviceOnce attr_set;
+    if (hipError_t e = set_max_dyn_lds_once((const void*)kern, lds, attr_set); e != hipSuccess) return e;
+    const int numMt8 = (a.Mq / BM + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(numMt8 * (2 * C / BN)), dim3(WR * WC * 64), lds, st, a);
+    return hipGetLastError();
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
-// Per-layer operands (once, on the first call that takes this path): G, V and the bias planes of layers 1 .. 7 of every flow
 // group rows per block: frame groups (dilations >= 32) B x 4 ceil(T / 16) per phase, mixed groups (dilation 16) B x ceil(T / 2)
 // per p0, both padded to the 128-row tile
 static inline int frame_group_rows(int BT, int T) { return ((BT / T) * frame_groups_per_utt(T) + 127) / 128 * 128; }
 static inline int mixed_group_rows(int BT, int T) { return ((BT / T) * mixed_groups_per_utt(T) + 127) / 128 * 128; }
 
-// Per-layer operands (once, on the first call that takes this path): G and V of layers 1 .. 7 of every flow
-int waveglow_build_wino(tts_hip_engine* e) {
+// Per-layer operands (on the first call that takes this path): G for layers 1 .. 7 of every flow; V for the phase groups
+// (dilations 2 - 8: weight combinations over the group's four phases) and the mixed groups (dilation 16).  The frame groups
+// (dilations >= 32) need none in the fused form -- their products' conditioning weights are chunk ranges of cond_Bt itself --
+// and six column-selected copies per phase ([32][6][1024][224], 176 MB per layer) in the three-pass form, built only when that
+// form is asked for (`legacy_frames`).  3.6 GB in all (three-pass: + 6.3 GB).  A failed allocation frees what this call built.
+int waveglow_build_wino(tts_hip_engine* e, bool legacy_frames) {
     WaveGlowDev& wg = e->wg;
-    if (wg.wino_ready) return TTS_HIP_OK;
+    if (wg.wino_ready && (!legacy_frames || wg.wino_legacy_ready)) return TTS_HIP_OK;
     hipStream_t st = e->stream;
+    std::vector<void*> fresh;                              // this call's allocations (moved to wg.allocs on success)
+    auto fail = [&](int rc) {
+        (void)hipStreamSynchronize(st);
+        for (void* p : fresh) (void)hipFree(p);
+        for (int k = 0; k < 12; ++k)
+            for (int i = 1; i < 8; ++i) {
+                WgLayerDev& ly = wg.flow[k].layer[i];
+                if (!wg.wino_ready) ly.wino_G = ly.wino_V = nullptr;
+                if (!wg.wino_legacy_ready) ly.wino_Vf = nullptr;
+            }
+        return rc;
+    };
     for (int k = 0; k < 12; ++k)
         for (int i = 1; i < 8; ++i) {
             WgLayerDev& ly = wg.flow[k].layer[i];
             const int d = 1 << i;
             int rc;
-            if ((rc = dev_alloc(e, (size_t)6 * 2 * C * C, &ly.wino_G, wg.allocs, false))) return rc;
-            hipLaunchKernelGGL(wino4_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
-            if (d == 16) {                                 // products 1 .. 4 carry the whole conditioning (K = 320)
-                if ((rc = dev_alloc(e, (size_t)16 * 4 * 2 * C * KMEL, &ly.wino_V, wg.allocs, false))) return rc;
-                hipLaunchKernelGGL(wino4_cond_weights_mixed_kernel, dim3(blocks_for((long long)16 * 2 * C * KMEL)), dim3(256), 0, st,
-                                   ly.cond_Bt, ly.wino_V);
-            } else {
-                const int ngp = d < NPH ? NPH / 4 : NPH;   // weight sets: group phases, or phases
-                if ((rc = dev_alloc(e, (size_t)ngp * 6 * 2 * C * K4, &ly.wino_V, wg.allocs, false))) return rc;
-                if (d < NPH)
-                    hipLaunchKernelGGL(wino4_cond_weights_kernel, dim3(blocks_for((long long)ngp * 6 * 2 * C * K4)), dim3(256), 0,
-                                       st, ly.cond_Bt, ly.wino_V, d);
-                else
-                    hipLaunchKernelGGL(wino4_cond_weights_frames_kernel, dim3(blocks_for((long long)ngp * 6 * 2 * C * K4)),
-                                       dim3(256), 0, st, ly.cond_Bt, ly.wino_V);
+            if (!wg.wino_ready) {
+                if ((rc = dev_alloc(e, (size_t)6 * 2 * C * C, &ly.wino_G, fresh, false))) return fail(rc);
+                hipLaunchKernelGGL(wino4_weights_kernel, dim3(blocks_for(2 * C * C)), dim3(256), 0, st, ly.in_Bt, ly.wino_G);
+                if (d == 16) {                             // products 1 .. 4 carry the whole conditioning (K = 320)
+                    if ((rc = dev_alloc(e, (size_t)16 * 4 * 2 * C * KMEL, &ly.wino_V, fresh, false))) return fail(rc);
+                    hipLaunchKernelGGL(wino4_cond_weights_mixed_kernel, dim3(blocks_for((long long)16 * 2 * C * KMEL)), dim3(256), 0,
+                                       st, ly.cond_Bt, ly.wino_V);
+                } else if (d < NPH) {                      // eight group phases
+                    if ((rc = dev_alloc(e, (size_t)(NPH / 4) * 6 * 2 * C * K4, &ly.wino_V, fresh, false))) return fail(rc);
+                    hipLaunchKernelGGL(wino4_cond_weights_kernel, dim3(blocks_for((long long)(NPH / 4) * 6 * 2 * C * K4)), dim3(256),
+                                       0, st, ly.cond_Bt, ly.wino_V, d);
+                }
             }
-            HIPCHK(e, hipGetLastError());
+            if (legacy_frames && !wg.wino_legacy_ready && d >= NPH) {
+                if ((rc = dev_alloc(e, (size_t)NPH * 6 * 2 * C * K4, &ly.wino_Vf, fresh, false))) return fail(rc);
+                hipLaunchKernelGGL(wino4_cond_weights_frames_kernel, dim3(blocks_for((long long)NPH * 6 * 2 * C * K4)), dim3(256), 0,
+                                   st, ly.cond_Bt, ly.wino_Vf);
+            }
+            if (hipError_t herr = hipGetLastError(); herr != hipSuccess)
+                return fail(set_err(e, TTS_HIP_EHIP, "waveglow_build_wino: %s", hipGetErrorString(herr)));
         }
-    HIPCHK(e, hipStreamSynchronize(st));
+    if (hipError_t herr = hipStreamSynchronize(st); herr != hipSuccess)
+        return fail(set_err(e, TTS_HIP_EHIP, "waveglow_build_wino: %s", hipGetErrorString(herr)));
+    wg.allocs.insert(wg.allocs.end(), fresh.begin(), fresh.end());
     wg.wino_ready = true;
+    if (legacy_frames) wg.wino_legacy_ready = true;
     return TTS_HIP_OK;
 }
 
@@ -420,16 +690,24 @@ struct MelPlanes {
 };
 
 // Workspace and the mel planes of one call (the mel does not change across layers and flows)
-int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T) {
+int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T, bool three_pass) {
     WaveGlowDev& wg = e->wg;
     hipStream_t st = e->stream;
     const int PRq = frame_group_rows(BT, T), PRm = mixed_group_rows(BT, T);
-    // U / P: six planes of 8 PR (phase groups), 32 PRq (frame groups) or 16 PRm (mixed groups) rows
+    // U (and the three-pass form's P): six planes of 8 PR (phase groups), 32 PRq (frame groups) or 16 PRm (mixed groups) rows
     const size_t rows = 6 * (size_t)std::max(std::max((long long)(NPH / 4) * PR, (long long)NPH * PRq), (long long)16 * PRm);
-    HIPCHK(e, wg.wino_U.ensure(rows * C * 4));
-    HIPCHK(e, wg.wino_P.ensure(rows * 2 * C * 4));
     const MelPlanes mp(PR, BT, T);
-    HIPCHK(e, wg.wino_mel.ensure(mp.total * 4));
+    auto room = [&](DevBuf& b, size_t bytes) -> int {       // out of memory is its own status: the caller keeps the direct form
+        const hipError_t err = b.ensure(bytes);
+        if (err == hipSuccess) return TTS_HIP_OK;
+        if (err == hipErrorOutOfMemory) (void)hipGetLastError();
+        return set_err(e, err == hipErrorOutOfMemory ? TTS_HIP_ENOMEM : TTS_HIP_EHIP, "waveglow_wino_begin: hipMalloc(%zu bytes) -> %s",
+                       bytes, hipGetErrorString(err));
+    };
+    int rc;
+    if ((rc = room(wg.wino_U, rows * C * 4))) return rc;
+    if (three_pass && (rc = room(wg.wino_P, rows * 2 * C * 4))) return rc;
+    if ((rc = room(wg.wino_mel, mp.total * 4))) return rc;
     float* base = wg.wino_mel.f();
     hipLaunchKernelGGL(wino4_mel_planes_kernel, dim3(blocks_for((long long)PR * K4)), dim3(256), 0, st, d_mel, base + mp.phases, PR, BT, T);
     for (int si = 0; si < 3; ++si)
@@ -453,6 +731,67 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     const bool phases = d <= 8, mixed = d == 16;
     const long long Mq = phases ? (long long)(NPH / 4) * PR : mixed ? (long long)16 * PRm : (long long)NPH * PRq;
     hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
+    if (wg.form_mode != 2) {                               // fused GEMM + output transform + gate (form 2: the three passes)
+        WinoFusedArgs a{};
+        a.U = U;
+        a.uplane = Mq * C;
+        a.G = ly.wino_G;
+        a.gplane = (long long)2 * C * C;
+        a.bias = ly.in_bias;
+        a.acts = acts_i;
+        a.Mq = (int)Mq;
+        a.phase_rows = phases ? PR : mixed ? PRm : PRq;
+        a.kind = phases ? 0 : mixed ? 2 : 1;
+        a.d = d;
+        a.PR = PR;
+        a.BT = BT;
+        a.T = T;
+        unsigned ccfg[6] = {0, 0, 0, 0, 0, 0};
+        auto cc = [](unsigned n1, unsigned b1, unsigned n2 = 0, unsigned b2 = 0) { return n1 | b1 << 5 | n2 << 9 | b2 << 12; };
+        if (phases) {                                      // V [8 group phases][6][1024][224]: [A | B | 0], [A | C], [B | C | 0]
+            a.mel = wg.wino_mel.f() + mp.phases;
+            a.mplane = (long long)PR * K4;
+            a.ldm = K4;
+            a.V = ly.wino_V;
+            a.vplane = (long long)2 * C * K4;
+            a.strideVp = 6 * a.vplane;
+            a.ldv = K4;
+            for (int p = 0; p < 6; ++p) ccfg[p] = cc(p == 1 || p == 2 ? 14 : 13, 0);
+        } else if (mixed) {                                // products 1 .. 4: K = 320 against V [16][4][1024][320]
+            a.mel = wg.wino_mel.f() + mp.mixed;
+            a.mplane = (long long)PRm * KMEL;
+            a.ldm = KMEL;
+            a.V = ly.wino_V;
+            a.vplane = (long long)2 * C * KMEL;
+            a.strideVp = 4 * a.vplane;
+            a.ldv = KMEL;
+            a.pofs = 1;
+            for (int p = 1; p < 5; ++p) ccfg[p] = cc(KMEL / 16, 0);
+        } else {                                           // frame groups: chunk ranges of cond_Bt [32 phases][1024][320]
+            a.mel = wg.wino_mel.f() + mp.frames[i - 5];
+            a.mplane = (long long)PRq * K4;
+            a.ldm = K4;
+            a.V = ly.cond_Bt;
+            a.vplane = 0;
+            a.strideVp = (long long)2 * C * KMEL;
+            a.ldv = KMEL;
+            ccfg[0] = ccfg[5] = cc((SA + SB) / 16, 0);                         // [A | B]
+            ccfg[1] = ccfg[2] = cc(SA / 16, 0, SC / 16, (SA + SB) / 16);       // [A | C]
+            ccfg[3] = ccfg[4] = cc((SB + SC) / 16, SA / 16);                   // [B | C]
+        }
+        for (int p = 0; p < 6; ++p) (p < 4 ? a.cfg_lo : a.cfg_hi) |= (unsigned long long)ccfg[p] << (16 * (p & 3));
+        timing_begin(e, 0);
+        switch (wg.form_mode) {                            // forms >= 3: tile / pipeline variants kept for measurement
+            case 3: HIPCHK(e, (launch_wino_fused<2, 2, 4, 2>(a, st))); break;
+            case 4: HIPCHK(e, (launch_wino_fused<4, 1, 3, 2>(a, st))); break;
+            case 5: HIPCHK(e, (launch_wino_fused<4, 2, 3, 1>(a, st))); break;
+            case 6: HIPCHK(e, (launch_wino_fused<4, 2, 6, 1>(a, st))); break;
+            case 7: HIPCHK(e, (launch_wino_fused<2, 2, 6, 2>(a, st))); break;
+            default: HIPCHK(e, (launch_wino_fused<2, 2, 3, 2>(a, st))); break;
+        }
+        timing_end(e);
+        return TTS_HIP_OK;
+    }
     GemmArgs g{};
     g.M = (int)Mq;
     g.N = 2 * C;
@@ -473,7 +812,7 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
         g.seg[1] = ASeg{wg.wino_mel.f() + (phases ? mp.phases : mp.frames[i - 5]), K4, 0, K4, K4, SEG_FRAME_Z, 0, (long long)g.phase_rows, 0};
         g.Bt = ly.wino_G;
         g.strideBz = gplane;
-        g.Bt2 = ly.wino_V;
+        g.Bt2 = phases ? ly.wino_V : ly.wino_Vf;
         g.ldb2 = K4;
         g.strideB2p = (long long)6 * 2 * C * K4;
         g.strideB2z = (long long)2 * C * K4;

@@ -17,6 +17,11 @@ import torch
 import torch.distributed as dist
 
 
+# What the last scatter / gather on this rank did (the GPU test asserts the device-resident path through these):
+# 'scatter_h2d' / 'gather_h2d' / 'gather_d2h' count host<->device copies of the token / waveform payloads made by this module.
+last_transfer = {'scatter_h2d': 0, 'gather_h2d': 0, 'gather_d2h': 0, 'gather_device_resident': False}
+
+
 def partition(lengths, world: int):
     """Longest-first round-robin: returns `world` lists of utterance indices (stable for equal lengths)."""
     order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
@@ -55,22 +60,24 @@ def scatter_tokens(tokens, speaker=None, src: int = 0, device=None):
     # equal-sized padded shards so that one scatter moves everything
     recv = torch.zeros((n_max, Tin), dtype=torch.int32, device=device)
     recv_spk = torch.zeros((n_max, E), dtype=torch.float32, device=device) if E else None
+    last_transfer['scatter_h2d'] = 0
     if rank == src:
-        chunks, spk_chunks = [], []
-        spk_t = torch.as_tensor(np.asarray(speaker), dtype=torch.float32) if E else None
-        for p in parts:
-            c = torch.zeros((n_max, Tin), dtype=torch.int32)
+        # the padded shards of all ranks are ONE [world, n_max, ...] tensor, gathered by row index on `device` after a single
+        # upload of the batch (the chunk list passed to scatter = its views); row N of the uploaded batch is the all-zero pad row
+        idx = torch.full((world, n_max), N, dtype=torch.int64)
+        for r, p in enumerate(parts):
             if p:
-                c[:len(p)] = tokens[p]
-            chunks.append(c.to(device))
-            if E:
-                s = torch.zeros((n_max, E), dtype=torch.float32)
-                if p:
-                    s[:len(p)] = spk_t[p]
-                spk_chunks.append(s.to(device))
+                idx[r, :len(p)] = torch.as_tensor(p, dtype=torch.int64)
+        idx = idx.to(device)
+        tok_d = torch.cat([tokens, torch.zeros((1, Tin), dtype=torch.int32)]).to(device)
+        last_transfer['scatter_h2d'] += 1 if device.type == 'cuda' else 0
+        chunks = list(tok_d[idx.reshape(-1)].reshape(world, n_max, Tin).unbind(0))
         dist.scatter(recv, chunks, src=src)
         if E:
-            dist.scatter(recv_spk, spk_chunks, src=src)
+            spk_t = torch.as_tensor(np.asarray(speaker), dtype=torch.float32)
+            spk_d = torch.cat([spk_t, torch.zeros((1, E), dtype=torch.float32)]).to(device)
+            last_transfer['scatter_h2d'] += 1 if device.type == 'cuda' else 0
+            dist.scatter(recv_spk, list(spk_d[idx.reshape(-1)].reshape(world, n_max, E).unbind(0)), src=src)
     else:
         dist.scatter(recv, None, src=src)
         if E:
@@ -81,39 +88,63 @@ def scatter_tokens(tokens, speaker=None, src: int = 0, device=None):
 
 def gather_audio(local_audio, local_counts, parts, dst: int = 0, device=None):
     """Every rank passes its waveforms [n_r, S_r] (float32, padded) and sample counts [n_r]; rank `dst` gets a list of
-    N numpy arrays in the original utterance order, the others get None."""
+    N numpy arrays in the original utterance order, the others get None.  Tensors that already live on `device` (what
+    `TTSPipeline.shard_fn` returns) go into the collective as they are; host arrays (numpy, or CPU tensors under gloo) are
+    uploaded first.  The waveforms cross to the host once: rank `dst`'s copy of the gathered block."""
     world, rank = dist.get_world_size(), dist.get_rank()
     device = _device(device)
     n_max = max(1, max(len(p) for p in parts))
+    n_mine = len(parts[rank])
+    on_dev = lambda t: torch.is_tensor(t) and t.device == device
+    resident = device.type == 'cuda' and on_dev(local_audio) and on_dev(local_counts)
+    last_transfer.update(gather_h2d=0, gather_d2h=0, gather_device_resident=bool(resident))
     counts = torch.zeros(n_max, dtype=torch.int64, device=device)
-    if len(parts[rank]):
-        counts[:len(parts[rank])] = torch.as_tensor(np.asarray(local_counts), dtype=torch.int64).to(device)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts)
-    s_max = max(1, int(max(int(c.max()) for c in all_counts)))
+    if n_mine:
+        if not on_dev(local_counts):
+            last_transfer['gather_h2d'] += 1 if device.type == 'cuda' else 0
+            local_counts = torch.as_tensor(np.asarray(local_counts.cpu() if torch.is_tensor(local_counts) else local_counts),
+                                           dtype=torch.int64).to(device)
+        counts[:n_mine] = local_counts.to(torch.int64)
+    all_counts = torch.zeros((world, n_max), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_counts, counts) if dist.get_backend() == 'nccl' else _all_gather_rows(all_counts, counts)
+    counts_h = all_counts.cpu()                                   # [world, n_max] sample counts: every rank sizes its buffer
+    s_max = max(1, int(counts_h.max()))
     buf = torch.zeros((n_max, s_max), dtype=torch.float32, device=device)
-    if len(parts[rank]):
-        la = torch.as_tensor(local_audio, dtype=torch.float32).to(device)
-        buf[:la.shape[0], :min(s_max, la.shape[1])] = la[:, :s_max]
+    if n_mine:
+        if not on_dev(local_audio):
+            last_transfer['gather_h2d'] += 1 if device.type == 'cuda' else 0
+            local_audio = torch.as_tensor(np.asarray(local_audio.cpu() if torch.is_tensor(local_audio) else local_audio),
+                                          dtype=torch.float32).to(device)
+        w = min(s_max, int(local_audio.shape[1]))
+        buf[:local_audio.shape[0], :w] = local_audio[:, :w]
     gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, gathered, dst=dst)
     if rank != dst:
         return None
+    g = torch.stack(gathered).cpu().numpy()                       # the job's one device-to-host waveform copy
+    last_transfer['gather_d2h'] += 1 if device.type == 'cuda' else 0
+    c = counts_h.numpy()
     N = sum(len(p) for p in parts)
     out = [None] * N
     for r, p in enumerate(parts):
-        g = gathered[r].cpu().numpy()
-        c = all_counts[r].cpu().numpy()
         for row, idx in enumerate(p):
-            out[idx] = g[row, :int(c[row])].copy()
+            out[idx] = g[r, row, :int(c[r, row])].copy()
     return out
+
+
+def _all_gather_rows(dst, row):
+    """all_gather of one row per rank into `dst` [world, n] (gloo has no all_gather_into_tensor)."""
+    rows = [torch.zeros_like(row) for _ in range(dst.shape[0])]
+    dist.all_gather(rows, row)
+    for r, t in enumerate(rows):
+        dst[r] = t
 
 
 def synthesize_sharded(tokens, synth_fn, speaker=None, src: int = 0, device=None):
     """scatter -> `synth_fn(local_tokens, local_speaker) -> (audio [n, S], counts [n])` on every rank -> gather."""
     local_tok, local_spk, parts = scatter_tokens(tokens, speaker, src=src, device=device)
     if local_tok.shape[0]:
-        audio, counts = synth_fn(local_tok, local_spk)
+        audio, counts = synth_fn(local_tok, local_spk)             # numpy arrays or tensors (device tensors stay on the device)
     else:
         audio, counts = np.zeros((0, 1), np.float32), np.zeros((0,), np.int64)
     return gather_audio(audio, counts, parts, dst=src, device=device)

@@ -134,6 +134,9 @@ class HipEngine:
         else:
             out = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
             sp = None
+            # the block may have pending readers / writers on torch's current stream (the caching allocator reuses it in that
+            # stream's order only); the fill runs on the engine's own stream
+            self._order_after_torch()
         self._check(self._lib.tts_hip_random_fill(self._h, kind, u64(seed), u64(offset), ctypes.c_void_p(out.data_ptr()),
                                                   out.numel(), sp), 'random_fill')
         if stream is None:
@@ -364,30 +367,35 @@ class HipEngine:
             device = torch.device('cuda', self.device)
             mk = lambda shape, dt=None: torch.zeros(shape, dtype=dt or torch.float32, device=device)
             ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-            if stream is not None:                   # conversions and zero-filled outputs are ordered on `stream` itself
-                scope = self._enter_stream(stream)
-                scope.__enter__()
             if prenet_masks is not None:
                 self._check_device(prenet_masks)
-                masks_in = prenet_masks
-                prenet_masks = prenet_masks.to(device=device, dtype=torch.float32).contiguous()
-                if stream is not None:
-                    self._used_on(stream, masks_in, prenet_masks)
+            if stream is not None:                   # conversions and zero-filled outputs are ordered on `stream` itself
+                scope = self._enter_stream(stream)
             i32 = torch.int32
         else:
             mk = lambda shape, dt=None: np.zeros(shape, dtype=dt or np.float32)
             ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-            if prenet_masks is not None:
-                prenet_masks = np.ascontiguousarray(prenet_masks, dtype=np.float32)
             i32 = np.int32
-        if prenet_masks is not None and tuple(prenet_masks.shape) != (B, max_len, 2, 256):
-            raise ValueError(f'prenet_masks must be [B, max_len, 2, 256], got {tuple(prenet_masks.shape)}')
-        mel, dec, stop = mk((B, max_len, 80)), mk((B, max_len, 80)), mk((B, max_len))
-        attn = mk((B, max_len, Tin)) if want_attention else None
-        lengths = mk((B,), i32)
+
+        def prepare():
+            masks = prenet_masks
+            if masks is not None and dev:
+                masks = masks.to(device=device, dtype=torch.float32).contiguous()
+                if stream is not None:
+                    self._used_on(stream, prenet_masks, masks)
+            elif masks is not None:
+                masks = np.ascontiguousarray(masks, dtype=np.float32)
+            if masks is not None and tuple(masks.shape) != (B, max_len, 2, 256):
+                raise ValueError(f'prenet_masks must be [B, max_len, 2, 256], got {tuple(masks.shape)}')
+            return (masks, mk((B, max_len, 80)), mk((B, max_len, 80)), mk((B, max_len)),
+                    mk((B, max_len, Tin)) if want_attention else None, mk((B,), i32))
+
         if scope is not None:
-            scope.__exit__(None, None, None)
+            with scope:                              # (a failing conversion must not leave the caller's stream switched)
+                prenet_masks, mel, dec, stop, attn, lengths = prepare()
             self._used_on(stream, mel, dec, stop, attn, lengths)
+        else:
+            prenet_masks, mel, dec, stop, attn, lengths = prepare()
         steps = ctypes.c_int32(0)
         sp = self._order_after_torch(stream) if dev else None
         win = int(attn_mask_win_len) if attn_mask_win_len is not None else 0
@@ -432,6 +440,25 @@ class HipEngine:
     def last_waveglow_form(self) -> str:
         """'winograd' or 'direct' for the last `waveglow_infer` call on this handle ('none' before the first)."""
         return {1: 'winograd', 0: 'direct'}.get(self._lib.tts_hip_last_waveglow_form(self._h), 'none')
+
+    def waveglow_probe_acts(self, mel, z=None, sigma: float = 1.0, flow: int = 11, layer: int = 1):
+        """Test hook (tts_hip_waveglow_probe_acts): the gated activations [B, T*32, 512] of WN layer `layer` of flow `flow` on
+        the fp32 path, in the form `set_waveglow_form` selects -- the values before the res/skip and `end` convolutions."""
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        if mel.ndim != 3 or mel.shape[2] != 80:
+            raise ValueError(f'mel must be [B, T, 80], got {mel.shape}')
+        B, T = mel.shape[:2]
+        zp = None
+        if z is not None:
+            z = np.ascontiguousarray(z, dtype=np.float32)
+            if z.shape != (B, T * 32, 8):
+                raise ValueError(f'z must be [B, T*32, 8] = {(B, T * 32, 8)}, got {z.shape}')
+            zp = z.ctypes.data_as(ctypes.c_void_p)
+        out = np.empty((B, T * 32, 512), dtype=np.float32)
+        self._check(self._lib.tts_hip_waveglow_probe_acts(
+            self._h, mel.ctypes.data_as(ctypes.c_void_p), B, T, zp, float(sigma), int(flow), int(layer),
+            out.ctypes.data_as(ctypes.c_void_p), MEM_HOST), 'waveglow_probe_acts')
+        return out
 
     # ------------------------------------------------------------------ mel-STFT
     def mel_stft(self, audio, stream=None):

@@ -14,17 +14,26 @@ PAD_MEL_VALUE = -11.0
 
 
 class TTSPipeline:
-    def __init__(self, engine, seed=None, vocoder_precision='f32', synthesizer_precision='f32'):
+    def __init__(self, engine, seed=None, vocoder_precision='f32', synthesizer_precision='f32', rank=None):
+        from .runtime import rank_stream
         self.engine = engine
         self.vocoder_precision = vocoder_precision      # 'f16': BASELINE.json configs 3 / 5
         self.synthesizer_precision = synthesizer_precision
         self._rng = np.random.default_rng(seed)
         self._seed = int(seed) if seed is not None else int(np.random.SeedSequence().generate_state(2, np.uint32).view(np.uint64)[0])
+        # one job-wide seed on every rank: each rank draws from its own key (ranks synthesize different shards; with one key
+        # they would all start at offset 0 and give different utterances the same noise)
+        if rank is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self._seed = rank_stream(self._seed, rank)
         self._offset = 0                                # running block offset in the engine's device-side Philox stream
 
     def synthesize_tokens(self, tokens, speaker=None, max_length=10.0, deterministic=False, prenet_masks=None, z=None,
-                          sigma=1.0, early_stopping=True, round_frames_to=8):
-        """tokens int32 [B, Tin] (0 = pad) -> (list of B float32 waveforms, lengths [B] in frames, steps run)."""
+                          sigma=1.0, early_stopping=True, round_frames_to=8, on_device=False):
+        """tokens int32 [B, Tin] (0 = pad) -> (list of B float32 waveforms, lengths [B] in frames, steps run).
+        `on_device`: nothing is copied to the host -- returns (audio [B, S] float32 device tensor, zero beyond each row's
+        samples, sample counts [B] int64 device tensor, steps run)."""
         import torch
         eng = self.engine
         dev = torch.device('cuda', eng.device)
@@ -49,6 +58,8 @@ class TTSPipeline:
         steps = eng.last_steps
         T = int(lengths.max())
         if T <= 0:
+            if on_device:
+                return torch.zeros((B, 1), dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.int64, device=dev), steps
             return [np.zeros((0,), np.float32) for _ in range(B)], lengths.cpu().numpy(), steps
         if round_frames_to > 1:                         # keeps the WaveGlow workspace sizes (and M tiles) stable
             T = min(max_len, (T + round_frames_to - 1) // round_frames_to * round_frames_to)
@@ -63,18 +74,20 @@ class TTSPipeline:
             if z is not None:
                 z = as_dev(z, torch.float32)[:, :T * 32]
             audio = eng.waveglow_infer(mel.contiguous(), z=z, sigma=sigma, precision=self.vocoder_precision)
+        if on_device:
+            counts = lengths.to(torch.int64) * 256
+            keep = torch.arange(T * 256, device=dev)[None, :] < counts[:, None]
+            return torch.where(keep, audio, torch.zeros_like(audio)), counts, steps
         audio_h = audio.cpu().numpy()
         n = lengths.cpu().numpy()
         return [audio_h[b, :int(n[b]) * 256].copy() for b in range(B)], n, steps
 
     def shard_fn(self, **kwargs):
         """`synth_fn(local_tokens, local_speaker) -> (audio [n, S] zero padded, sample counts [n])` for
-        `distributed.synthesize_sharded`: this rank's share of the utterances through `synthesize_tokens(**kwargs)`."""
+        `distributed.synthesize_sharded`: this rank's share of the utterances through `synthesize_tokens(**kwargs)`.  Both
+        results are DEVICE tensors (the waveforms go from WaveGlow's output buffer straight into the RCCL gather; the only
+        device-to-host copy of the job is rank 0's, after the gather)."""
         def synth(local_tokens, local_speaker):
-            audios, n_frames, _ = self.synthesize_tokens(local_tokens, speaker=local_speaker, **kwargs)
-            counts = np.asarray([len(a) for a in audios], dtype=np.int64)
-            padded = np.zeros((len(audios), max(1, int(counts.max()) if len(audios) else 1)), np.float32)
-            for i, a in enumerate(audios):
-                padded[i, :len(a)] = a
-            return padded, counts
+            audio, counts, _ = self.synthesize_tokens(local_tokens, speaker=local_speaker, on_device=True, **kwargs)
+            return audio, counts
         return synth

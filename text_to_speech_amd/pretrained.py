@@ -56,10 +56,11 @@ def find_checkpoint(save_dir):
     for c in candidates:
         if os.path.exists(c):
             return c
-    found = sorted(glob.glob(os.path.join(save_dir, '*.weights.h5')), key=os.path.getmtime)
+    found = sorted(glob.glob(os.path.join(save_dir, '*.weights.h5')) + glob.glob(os.path.join(save_dir, '*.keras')),
+                   key=os.path.getmtime)
     if found:
         return found[-1]
-    raise FileNotFoundError(f'no Keras checkpoint (*.weights.h5) in {save_dir}')
+    raise FileNotFoundError(f'no Keras checkpoint (*.weights.h5 or *.keras) in {save_dir}')
 
 
 # What the engine implements of the reference's hyper-parameters (architectures/tacotron2_arch.py:59-135,
@@ -196,21 +197,22 @@ def read_model_dir(model_dir):
 
 
 def convert_model_dir(model_dir, out=None, cfg=None, force=False):
-    """Keras checkpoint of the directory -> TTSW file (default `<checkpoint>.ttsw`, reused while it is newer than the
-    checkpoint).  Returns (path, info)."""
+    """Keras checkpoint of the directory (`.weights.h5`, or a `.keras` archive: its model.weights.h5 member) -> TTSW file
+    (default `<checkpoint>.ttsw`, reused while it is newer than the checkpoint).  Returns (path, info)."""
     from .weights import save_ttsw
-    from .weights_import import from_keras_h5
+    from .weights_import import from_keras_file
     info = read_model_dir(model_dir)
     ckpt = info['checkpoint']
-    if not ckpt.endswith('.weights.h5'):
-        raise ValueError(f'{ckpt}: only `.weights.h5` checkpoints can be read directly (export `.keras` files with '
-                         'scripts/export_keras_weights.py where Keras runs)')
-    out = out or ckpt[:-len('.weights.h5')] + '.ttsw'
+    ext = next((x for x in ('.weights.h5', '.keras') if ckpt.endswith(x)), None)      # what CheckpointManager.load accepts (:196)
+    if ext is None:
+        raise ValueError(f'{ckpt}: only `.weights.h5` checkpoints and `.keras` archives can be read (TF `.index` checkpoints: '
+                         'export them with scripts/export_keras_weights.py where TensorFlow runs)')
+    out = out or ckpt[:-len(ext)] + '.ttsw'
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(ckpt):
         if cfg is None:
             cfg = Tacotron2Config(speaker_embedding_dim=info['speaker_embedding_dim'], vocab_size=info['vocab_size']) \
                 if info['model'] == 'tacotron2' else WaveGlowConfig()
-        tensors = from_keras_h5(ckpt, info['model'], cfg)
+        tensors = from_keras_file(ckpt, info['model'], cfg)
         # several ranks / processes may open a fresh directory at once: each writes its own temporary file and publishes it
         # atomically (a shared name let one writer truncate the file another had just finished)
         import tempfile

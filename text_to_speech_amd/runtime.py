@@ -15,8 +15,9 @@ Call contracts honoured:
 Randomness: like the reference (prenet dropout and z are sampled inside the graph, on the device:
 tacotron2_arch.py:197-201, waveglow_arch.py:272-274,299-302) the default path draws both ON THE GPU -- the engine's
 documented Philox4x32-10 stream (include/tts_hip.h, oracle/philox_ref.py), keyed by the runtime's seed and a running block
-offset -- so no host-made tensor crosses PCIe.  Explicit control stays: pass `prenet_masks` / `z`, or `deterministic=True`,
-or `seed=` (that call then starts at offset 0 of that seed's stream and is reproducible).
+offset -- so no host-made tensor crosses PCIe.  The dropout bits and the noise are separate streams of one seed (key = seed
+XOR a purpose constant in the high word: MASK_STREAM / NOISE_STREAM).  Explicit control stays: pass `prenet_masks` / `z`, or
+`deterministic=True`, or `seed=` (that call then starts at offset 0 of that seed's streams and is reproducible).
 """
 from __future__ import annotations
 
@@ -27,6 +28,19 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from .engine import HipEngine, Tacotron2InferenceOutput, _is_torch_cuda
+
+
+# An explicit `seed=` names one stream per PURPOSE: the prenet dropout bits and the WaveGlow noise of the same seed must not be
+# the same Philox blocks (both would start at offset 0 of one key and be correlated), so the purpose is XORed into the key's
+# high word.  The engine-level calls (HipEngine.waveglow_infer(seed=...), tts_hip_random_fill) take the key as given.
+MASK_STREAM = 0x4D41534B << 32          # "MASK"
+NOISE_STREAM = 0x5A4E5345 << 32         # "ZNSE"
+_U64 = (1 << 64) - 1
+
+
+def rank_stream(seed: int, rank: int) -> int:
+    """Key of rank `rank`'s stream under a job-wide seed: ranks synthesize different shards and must not draw identical noise."""
+    return (int(seed) ^ (((int(rank) + 1) * 0x9E3779B97F4A7C15) & _U64)) & _U64 if rank else int(seed) & _U64
 
 
 def sample_prenet_masks(rng, B, max_len):
@@ -168,15 +182,16 @@ class HipRuntime(Runtime):
         mask_seed = None
         if prenet_masks is None and not deterministic:
             if seed is not None:
-                mask_seed = (int(seed), 0)
+                mask_seed = ((int(seed) ^ MASK_STREAM) & _U64, 0)
             else:
-                mask_seed = (self._seed, self._offset)
+                mask_seed = ((self._seed ^ MASK_STREAM) & _U64, self._offset)
                 self._offset += (B * max_len * 512 + 3) // 4
-        # encoder reuse (the reference retries a sentence with fresh dropout, models/tts/tacotron2.py:160-179): device inputs
-        # are recognised by identity and version (no copy), host inputs by their bytes
+        # encoder reuse (the reference retries a sentence with fresh dropout, models/tts/tacotron2.py:160-179): inputs are
+        # recognised by CONTENT -- host inputs by their bytes, device inputs by comparing them on the device with the runtime's
+        # own copy of the batch that was encoded (an address / version key is not enough: the caching allocator hands the
+        # address of a freed token tensor to the next sentence's tensor of the same shape)
         if dev:
-            key = ('dev', tokens.data_ptr(), tokens._version, tuple(tokens.shape),
-                   None if speaker is None else (speaker.data_ptr(), getattr(speaker, '_version', 0), tuple(speaker.shape)))
+            key = self._device_key(tokens, speaker)
         else:
             spk_np = None if speaker is None else (speaker.detach().cpu().numpy() if _is_torch_cuda(speaker) else np.asarray(speaker))
             key = ('host', tokens.shape, tokens.astype(np.int32).tobytes(),
@@ -188,7 +203,7 @@ class HipRuntime(Runtime):
                 tokens, speaker=speaker, max_len=max_len, early_stopping=bool(early_stopping),
                 prenet_masks=prenet_masks, attn_mask_win_len=attn_mask_win_len, attn_mask_offset=int(attn_mask_offset or 0),
                 precision=precision or self.synthesizer_precision)
-        if self._encoded is not None and self._encoded[0] == key:
+        if self._encoded is not None and (self._encoded[0] is key if dev else self._encoded[0] == key):
             self.encoder_reuses += 1
         elif self._encoded is not None:
             # one encoded-batch handle per runtime, overwritten sentence after sentence: no device allocation per sentence,
@@ -213,6 +228,25 @@ class HipRuntime(Runtime):
             self._drop_encoded()
             raise
 
+    def _device_key(self, tokens, speaker):
+        """Key of a device token batch: the cached key itself when the contents equal the batch it was made from (one tiny
+        comparison kernel + a host read of its verdict), else a new key holding private copies of the inputs."""
+        import torch
+        spk_dev = speaker is not None and _is_torch_cuda(speaker)
+        if self._encoded is not None and self._encoded[0][0] == 'dev':
+            _, kept_tok, kept_spk = self._encoded[0]
+            same = tuple(kept_tok.shape) == tuple(tokens.shape) and (kept_spk is None) == (speaker is None)
+            if same and speaker is not None:
+                spk = speaker if spk_dev else torch.as_tensor(np.asarray(speaker), dtype=torch.float32)
+                same = tuple(kept_spk.shape) == tuple(spk.shape) and bool(torch.equal(kept_spk, spk.to(device=kept_spk.device, dtype=torch.float32)))
+            if same and bool(torch.equal(kept_tok, tokens.to(torch.int32))):
+                return self._encoded[0]
+        spk_copy = None
+        if speaker is not None:
+            spk_copy = (speaker if spk_dev else torch.as_tensor(np.asarray(speaker), dtype=torch.float32)).to(
+                device=tokens.device, dtype=torch.float32).clone()
+        return ('dev', tokens.to(torch.int32).clone(), spk_copy)
+
     def _drop_encoded(self):
         if self._encoded is not None:
             try:
@@ -230,9 +264,9 @@ class HipRuntime(Runtime):
         B, T = int(mel.shape[0]), int(mel.shape[1])
         if z is None and not deterministic:
             if seed is not None:
-                zs, zo = int(seed), 0
+                zs, zo = (int(seed) ^ NOISE_STREAM) & _U64, 0
             else:
-                zs, zo = self._seed, self._offset
+                zs, zo = (self._seed ^ NOISE_STREAM) & _U64, self._offset
                 self._offset += (B * T * 256 + 3) // 4
             return self.engine.waveglow_infer(mel, sigma=float(sigma), precision=precision or self.vocoder_precision,
                                               seed=zs, offset=zo)

@@ -21,6 +21,7 @@ CLI:  python -m text_to_speech_amd.weights_import --tacotron2 tacotron2.pt --wav
 from __future__ import annotations
 
 import argparse
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -316,6 +317,40 @@ def from_keras_h5(path, model: str, cfg=None):
     return _checked(out, manifest)
 
 
+def from_keras_archive(path, model: str, cfg=None):
+    """A Keras 3 `.keras` archive (`model.save(...)`, /root/reference/custom_train_objects/checkpoint_manager.py:155,196: the
+    manager writes and restores them beside `.weights.h5` files) -> manifest tensors.  The archive is a zip holding
+    `config.json`, `metadata.json` and `model.weights.h5`; that member is written by the same object-tree walk as
+    `save_weights` (keras.saving.saving_lib: `_save_state` behind both), so it goes through `from_keras_h5` unchanged once it
+    is a file: it is extracted to a temporary file beside nothing else (the pure-Python HDF5 reader seeks).  Only the weights
+    member is read -- the pickled / JSON model definition is never evaluated."""
+    import tempfile
+    import zipfile
+    if not zipfile.is_zipfile(path):
+        raise ValueError(f'{path}: not a zip archive (a `.keras` file is a zip with model.weights.h5 inside)')
+    with zipfile.ZipFile(path) as z:
+        members = [n for n in z.namelist() if n.rsplit('/', 1)[-1] == 'model.weights.h5']
+        if len(members) != 1:
+            raise ValueError(f'{path}: expected one model.weights.h5 member, found {members or "none"} in {z.namelist()[:8]}')
+        info = z.getinfo(members[0])
+        if info.file_size > (64 << 30):
+            raise ValueError(f'{path}: {members[0]} claims {info.file_size} bytes')
+        with tempfile.TemporaryDirectory(prefix='tts_keras_') as tmp:
+            out = os.path.join(tmp, 'model.weights.h5')
+            with z.open(info) as src, open(out, 'wb') as dst:          # (never extract by member name: no path traversal)
+                while True:
+                    block = src.read(1 << 24)
+                    if not block:
+                        break
+                    dst.write(block)
+            return from_keras_h5(out, model, cfg)
+
+
+def from_keras_file(path, model: str, cfg=None):
+    """`.weights.h5` or `.keras`, by extension (the two formats CheckpointManager.load accepts, checkpoint_manager.py:196)."""
+    return from_keras_archive(path, model, cfg) if str(path).endswith('.keras') else from_keras_h5(path, model, cfg)
+
+
 def _checked(tensors, manifest):
     out = OrderedDict()
     for name, shape in manifest.items():
@@ -424,8 +459,8 @@ def main(argv=None):
     ap.add_argument('--waveglow', help='NVIDIA WaveGlow checkpoint (.pt, weight norm allowed)')
     ap.add_argument('--keras-tacotron2', help='Keras variables of the Tacotron2 model (scripts/export_keras_weights.py output)')
     ap.add_argument('--keras-waveglow', help='Keras variables of the WaveGlow model (scripts/export_keras_weights.py output)')
-    ap.add_argument('--keras-h5-tacotron2', help="the reference's Tacotron2 `.weights.h5` checkpoint, read directly")
-    ap.add_argument('--keras-h5-waveglow', help="the reference's WaveGlow `.weights.h5` checkpoint, read directly")
+    ap.add_argument('--keras-h5-tacotron2', help="the reference's Tacotron2 `.weights.h5` checkpoint (or `.keras` archive), read directly")
+    ap.add_argument('--keras-h5-waveglow', help="the reference's WaveGlow `.weights.h5` checkpoint (or `.keras` archive), read directly")
     ap.add_argument('--speaker-embedding-dim', type=int, default=0, help='256 for the SV2TTS Tacotron2')
     ap.add_argument('-o', '--output', required=True, help='TTSW file to write')
     args = ap.parse_args(argv)
@@ -438,10 +473,10 @@ def main(argv=None):
         if args.keras_waveglow:
             tensors.update(from_keras_variables(load_file(args.keras_waveglow), 'waveglow'))
     if args.keras_h5_tacotron2:
-        tensors.update(from_keras_h5(args.keras_h5_tacotron2, 'tacotron2',
+        tensors.update(from_keras_file(args.keras_h5_tacotron2, 'tacotron2',
                                      Tacotron2Config(speaker_embedding_dim=args.speaker_embedding_dim)))
     if args.keras_h5_waveglow:
-        tensors.update(from_keras_h5(args.keras_h5_waveglow, 'waveglow'))
+        tensors.update(from_keras_file(args.keras_h5_waveglow, 'waveglow'))
     if args.tacotron2 or args.waveglow:
         import torch
     if args.tacotron2:
