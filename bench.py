@@ -52,18 +52,20 @@ K_REFERENCE = 3 * 512 + 640        # the reference formulation: taps + 640-chann
 
 
 def wino_in_layer_flops(B: int, T: int) -> float:
-    """FLOPs the Winograd form of the in-layer GEMM EXECUTES per launch, averaged over the 8 launches of a flow
-    (csrc/wn_wino.hip, F(4,3)): six K = 512 + 224 products on M / 4 group rows for the dilations 2, 4, 8 (groups of phases)
-    and 32, 64, 128 (groups of frames, group rows per phase padded to the 128-row tile); dilation 16 (two phases x two
-    frames) = four K = 512 + 320 products and, in a second launch, two K = 512 products."""
+    """FLOPs the Winograd form of the in-layer GEMM EXECUTES per launch, averaged over the 7 launches of a flow (one fused
+    kernel per layer, csrc/wn_wino.hip, F(4,3)): six products on M / 4 group rows -- K = 512 taps + the product's conditioning
+    chunks: 208 columns for products 0, 3, 4, 5 and 224 for products 1, 2 -- for the dilations 2, 4, 8 (groups of phases) and
+    32, 64, 128 (groups of frames, group rows per phase padded to the 128-row tile); dilation 16 (two phases x two frames):
+    four K = 512 + 320 products and two K = 512 products."""
     BT = B * T
     PR = (BT + 255) // 256 * 256                         # frame rows per phase block (256-row tiles)
     PRq = (B * ((T + 15) // 16 * 4) + 127) // 128 * 128
     PRm = (B * ((T + 1) // 2) + 127) // 128 * 128
-    phases = 6 * (8 * PR) * (512 + 224)
-    frames = 6 * (32 * PRq) * (512 + 224)
-    mixed = 4 * (16 * PRm) * (512 + 320) + 2 * (16 * PRm) * 512
-    return 2.0 * 1024 * (3 * phases + 3 * frames + mixed) / 8.0
+    k6 = 4 * (512 + 208) + 2 * (512 + 224)               # K summed over the six products
+    phases = (8 * PR) * k6
+    frames = (32 * PRq) * k6
+    mixed = (16 * PRm) * (4 * (512 + 320) + 2 * 512)
+    return 2.0 * 1024 * (3 * phases + 3 * frames + mixed) / 7.0
 
 
 def wn_in_layer_flops(M: int, k: int = K_EXECUTED) -> float:
@@ -298,6 +300,7 @@ def secondary_metrics(eng, dev, rank):
     secs = sum(len(a) for a in audio) / SAMPLE_RATE
     out['pipeline_batch8_f16_audio_seconds_per_s'] = secs / dt
     out['pipeline_batch8_f16_ms'] = dt * 1e3
+    out.update(config5_streaming(eng))
     # mel-STFT (rows C1 / C2 of SURVEY 8a): 8 x 204 800 samples, DFT as a windowed real / imaginary basis product + mel + log.
     # Executed work as written by the reference: 2 * 1024 * 1026 + 2 * 513 * 80 FLOP per frame.
     wav = torch.from_numpy(np.random.default_rng(9).uniform(-0.5, 0.5, (BATCH, FRAMES * 256)).astype(np.float32)).to(dev)
@@ -312,6 +315,48 @@ def secondary_metrics(eng, dev, rank):
     out['mel_stft_batch8_ms'] = dt * 1e3
     out['mel_stft_audio_seconds_per_s'] = BATCH * FRAMES * 256 / SAMPLE_RATE / dt
     out['mel_stft_tflops_as_written'] = n_fr * (2.0 * 1024 * 1026 + 2.0 * 513 * 80) / dt / 1e12
+    return out
+
+
+def config5_streaming(eng):
+    """BASELINE.json configs[4]: `stream()`-style long-form synthesis, 64 sentences one after the other (token counts cycling
+    50 .. 200, the decoder on its default machine at batch 1, both models in their fp16 modes, noise and dropout off so that the
+    two runs do the same work): sequential, and with Tacotron2(n + 1) overlapped with WaveGlow(n) on a second engine handle
+    (`predict(overlap=True)`).  Synthetic weights never fire the stop token: every sentence decodes 4 frames per token."""
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import Tacotron2Config, WaveGlowConfig
+    from text_to_speech_amd.engine import HipEngine
+    from text_to_speech_amd.runtime import HipRuntime
+    from text_to_speech_amd.tacotron2 import Tacotron2
+    from text_to_speech_amd.waveglow import WaveGlow
+    out = {}
+    eng2 = HipEngine(eng.device)                                         # the overlapped run's vocoder lane (`eng` holds both models)
+    try:
+        eng2.load_state(weights.synth_waveglow(WaveGlowConfig(), seed=1234))
+        eng2.finalize()
+        model = Tacotron2(HipRuntime('t', model='tacotron2', engine=eng, seed=0, synthesizer_precision='f16'))
+        voc_same = WaveGlow(HipRuntime('w', model='waveglow', engine=eng, seed=0, vocoder_precision='f16'))
+        voc_own = WaveGlow(HipRuntime('w2', model='waveglow', engine=eng2, seed=0, vocoder_precision='f16'))
+        rng = np.random.default_rng(0)
+        letters = np.array(list('abcdefghijklmnopqrstuvwxyz     '))
+        lens = [50, 70, 90, 110, 130, 150, 170, 200]
+        texts = [''.join(rng.choice(letters, lens[i % 8])).strip() + f' {i}.' for i in range(64)]
+        kw = dict(max_length=4., deterministic=True, save=False, return_results=False)
+        model.predict(texts[:2], vocoder=voc_same, **kw)
+        model.predict(texts[:2], vocoder=voc_own, overlap=True, **kw)
+        for name, voc, ov in (('sequential', voc_same, False), ('overlapped', voc_own, True)):
+            secs = []
+            t0 = time.perf_counter()
+            model.predict(texts, vocoder=voc, overlap=ov, callbacks=[lambda time, **_: secs.append(time)], **kw)
+            dt = time.perf_counter() - t0
+            out[f'config5_stream64_f16_{name}_ms'] = dt * 1e3
+            out[f'config5_stream64_f16_{name}_x_realtime'] = sum(secs) / dt
+        out['config5_stream64_audio_seconds'] = float(sum(secs))
+        out['config5_stream64_decoder_path'] = eng.last_decoder_mode
+    except Exception as exc:                                         # a secondary figure never costs the line
+        out['config5_stream64_error'] = f'{type(exc).__name__}: {exc}'
+    finally:
+        eng2.close()
     return out
 
 
@@ -450,13 +495,13 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
         flops = wino_in_layer_flops(B, T) if wino else wn_in_layer_flops(M)
         achieved = flops / (avg_us * 1e-6) / 1e12
         if wino:
-            kernel = ('gemm_f32_kernel<4,1,{2|1},4,16,{2|3},TAG_WN_WINO=4,0,PIPE_DMA>, one z slice per Winograd product (WN in-layer '
-                      'GEMM of layers 1-7 in its F(4,3) form: six K = 512 + 224 products on M / 4 group rows -- 256-row tiles for the '
-                      'phase groups of dilations 2, 4, 8, 128-row tiles for the frame groups of dilations 32, 64, 128; dilation 16: '
-                      'four K = 512 + 320 products + two K = 512 products in two launches; average over the 8 launches of a flow; '
-                      'the pre-pass and the combine + gate pass are separate HBM-bound kernels)')
-            # per launch (F(4,3)): six transformed-input planes in, six product planes out, weights
-            alg_bytes = (6 * (M // 4) * 512 + 6 * (M // 4) * 1024 + 6 * 1024 * 512 + 8 * 6 * 1024 * 224) * 4.0
+            kernel = ('wino4_fused2_kernel (csrc/wn_wino.hip): WN in-layer GEMM of layers 1-7 in its Winograd F(4,3) form, ONE launch per '
+                      'layer -- the six input tiles of a K chunk by LDS-DMA, input transform in the operand reads, six products (K = 512 + '
+                      '208 / 224 conditioning columns; dilation 16: 512 + 320 / 512) as accumulator sets of a 64 x 128 block tile, output '
+                      'transform + bias + gate in the epilogue; average over the 7 launches of a flow')
+            # per launch: the residual stream in, the gated activations out, the six tap-combination planes and the conditioning
+            # planes of the layer's group kind (phase groups: [8][6][1024][224]), the mel planes
+            alg_bytes = (M * 512 + M * 512 + 6 * 1024 * 512 + 8 * 6 * 1024 * 224 + 6 * B * T * 224) * 4.0
         else:
             kernel = ('gemm_f32_kernel<4,1,2,4,16,2,TAG_WN_IN=1,3,PIPE_DMA> (WN in-layer implicit GEMM, layers 1-7 of each flow; '
                       'K = 1536 taps + 320 folded conditioning)')
@@ -464,6 +509,8 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
         roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                     'flops_per_launch': flops,
+                    # the same launch counted in the direct (K = 1856) and in the reference's (K = 2176) formulation: one launch =
+                    # one layer in both forms (round 3's figures divided one layer's FLOPs by the average of 8 launches for 7 layers)
                     'direct_formulation_tflops': wn_in_layer_flops(M, K_EXECUTED) / (avg_us * 1e-6) / 1e12,
                     'reference_formulation_tflops': wn_in_layer_flops(M, K_REFERENCE) / (avg_us * 1e-6) / 1e12,
                     'traffic': pmc_traffic_bytes(B, T),
@@ -482,7 +529,7 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                    'world_size': world, 'backend': 'nccl (RCCL)' if distributed else 'single process',
                    'weights': 'seeded synthetic (rng 1234)',
                    'arithmetic': 'fp32 operands, fp32 MFMA accumulate; dilated convolutions of WN layers 1-7 in their '
-                                 + ('Winograd F(4,3) form along the tap axis (csrc/wn_wino.hip; 6.0e-7 '
+                                 + ('Winograd F(4,3) form along the tap axis (csrc/wn_wino.hip, one fused kernel per layer; 6.0e-7 '
                                     'waveform RMS error against the oracle, the direct form 4.96e-7: tests/test_waveglow_gpu.py)'
                                     if form == 'winograd'
                                     else 'direct three-tap form')},

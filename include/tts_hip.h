@@ -172,11 +172,14 @@ int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode);
 int tts_hip_last_decoder_mode(const tts_hip_engine* e);
 
 /* How the fp32 WaveGlow path evaluates the k = 3 dilated convolution of WN layers 1 .. 7 (waveglow_arch.py:117-127).
- * form 1 (default): Winograd minimal filtering along the tap axis for calls of 384 frames or more (any utterance
- * length; csrc/wn_wino.hip) -- F(4,3), six
- * products per four outputs: K per output ~800 + 320 instead of 1536 + 320, fp32 operands and accumulators, results
- * within fp32 rounding of the direct form (6.0e-7 vs 5.0e-7 waveform RMS error against the oracle);
- * form 0: always the direct form.                                                                                      */
+ * form 1 (default): Winograd minimal filtering along the tap axis for calls of 384 frames or more (any utterance length;
+ * csrc/wn_wino.hip) -- F(4,3), six products per four outputs: K per output ~800 + 320 instead of 1536 + 320, fp32 operands
+ * and accumulators, ONE kernel per layer (input transform in the operand reads, the six products as accumulator sets of one
+ * block, output transform + gate in the epilogue); results within fp32 rounding of the direct form (6.0e-7 vs 5.0e-7
+ * waveform RMS error against the oracle);
+ * form 0: always the direct form;
+ * forms 2, 3 (measurement only, same results as form 1): the three-pass form of round 3 (pre-pass, per-product GEMM, combine
+ * pass) and the fused GEMM behind the pre-pass.                                                                         */
 int tts_hip_set_waveglow_form(tts_hip_engine* e, int form);
 /* Which one the last tts_hip_waveglow_infer* call on this handle used: 1 Winograd, 0 direct, -1 before the first call.  */
 int tts_hip_last_waveglow_form(const tts_hip_engine* e);

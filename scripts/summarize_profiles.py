@@ -64,7 +64,7 @@ for sub in ('pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_SQ_VALU_MFMA_BUSY_CYCLES'):
         for cn, vals in cs.items():
             merged.setdefault(kn, {})[cn] = vals
 for kn, cs in merged.items():
-    if 'gemm_f32_kernel' not in kn and 'wn_' not in kn:
+    if 'gemm_f32_kernel' not in kn and 'wn_' not in kn and 'wino4' not in kn:
         continue
     e = {'launches': max(len(v) for v in cs.values())}
     for cn, vals in cs.items():
@@ -99,7 +99,7 @@ for prec in ('f16', 'f16x3'):
             stats[r['Name']] = float(r['AverageNs'])
     outp = {}
     for kn, cs in m.items():
-        if 'gemm_f32_kernel' not in kn and 'wn_' not in kn:
+        if 'gemm_f32_kernel' not in kn and 'wn_' not in kn and 'wino4' not in kn:
             continue
         e = {'launches': max(len(v) for v in cs.values())}
         for cn, vals in cs.items():
@@ -120,7 +120,10 @@ print('wrote', f'{tag}_pmc_counters.json')
 # Winograd form (csrc/wn_wino.hip) that is one template in two tile heights (TAG 4: 256 rows for pairs of phases, 128 rows
 # for pairs of frames): launch-weighted means over both; without it, the direct kernel.
 WINO = 'gemm_f32_kernel<4, 1, '
-cands = [(kn, e) for kn, e in summary['kernels'].items() if WINO in kn and ', 4, 0, 1, false, 3, 1>' in kn and 'FETCH_SIZE_mean' in e]
+# round 4: ONE fused kernel per layer (wino4_fused2_kernel)
+cands = [(kn, e) for kn, e in summary['kernels'].items() if 'wino4_fused2_kernel' in kn and 'FETCH_SIZE_mean' in e]
+if not cands:
+    cands = [(kn, e) for kn, e in summary['kernels'].items() if WINO in kn and ', 4, 0, 1, false, 3, 1>' in kn and 'FETCH_SIZE_mean' in e]
 if not cands:
     cands = [(kn, e) for kn, e in summary['kernels'].items() if IN_LAYER in kn and 'FETCH_SIZE_mean' in e][:1]
 if cands:

@@ -1,5 +1,6 @@
-"""Fused Winograd form (form 1 and the measurement variants 3 - 7) against the three-pass form (2) on one shape: call time,
-average in-layer launch time (HIP events) and the waveform difference from the three-pass result.  argv: B T [forms ...]"""
+"""The Winograd forms of the fp32 in-layer GEMM on one shape: 2 = three passes (round 3), 3 = fused GEMM behind the pre-pass,
+1 = fused GEMM with the input transform in its operand reads (default), 0 = direct form: call time, average in-layer launch
+time (HIP events) and the waveform difference from the first form listed.  argv: B T [forms ...]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,7 @@ from text_to_speech_amd import weights
 from text_to_speech_amd.config import WaveGlowConfig
 from text_to_speech_amd.engine import HipEngine
 B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8, 800)
-forms = [int(a) for a in sys.argv[3:]] or [2, 1, 3, 4, 5, 6, 7, 0]
+forms = [int(a) for a in sys.argv[3:]] or [2, 3, 1, 0]
 eng = HipEngine(0)
 eng.load_state(weights.synth_waveglow(WaveGlowConfig(), seed=1234)); eng.finalize()
 mel = torch.from_numpy(np.random.default_rng(7).uniform(-11.5, 1.2, (B, T, 80)).astype(np.float32)).cuda()

@@ -202,7 +202,7 @@ void tacotron2_graphs_clear(tts_hip_engine* e);
 
 // Winograd form of the WN in-layer GEMM (wn_wino.hip)
 int waveglow_build_wino(tts_hip_engine* e, bool legacy_frames);
-int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T, bool three_pass);
+int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T, int form);
 int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const float* x, float* acts_i, int PR, int BT, int T);
 // timing helpers (engine.hip)
 void timing_begin(tts_hip_engine* e, int kind);

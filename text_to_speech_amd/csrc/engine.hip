@@ -471,8 +471,8 @@ int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode) {
 int tts_hip_last_decoder_mode(const tts_hip_engine* e) { return e ? e->taco.last_path : -1; }
 
 int tts_hip_set_waveglow_form(tts_hip_engine* e, int form) {
-    if (!e || form < 0 || form > 7)
-        return set_err(e, TTS_HIP_EINVAL, "set_waveglow_form: form must be 0 (direct), 1 (Winograd when the call shape allows it) or a measurement form 2 .. 7");
+    if (!e || form < 0 || form > 3)
+        return set_err(e, TTS_HIP_EINVAL, "set_waveglow_form: form must be 0 (direct), 1 (Winograd when the call shape allows it) or a measurement form (2, 3)");
     e->wg.form_mode = form;
     return TTS_HIP_OK;
 }

@@ -790,7 +790,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
         int rc = free_b < need ? TTS_HIP_ENOMEM : waveglow_build_wino(e, three_pass);
         bool oom = rc == TTS_HIP_ENOMEM;
         if (!rc) {
-            rc = waveglow_wino_begin(e, d_mel, PR, BT, T, three_pass);
+            rc = waveglow_wino_begin(e, d_mel, PR, BT, T, wg.form_mode);
             oom = rc == TTS_HIP_ENOMEM;
         }
         if (rc && !oom) return rc;

@@ -612,6 +612,367 @@ hipError_t launch_wino_fused(const WinoFusedArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fused form WITHOUT the pre-pass: the input transform moves into the operand reads.  The K loop of the tap part runs chunk
+// by chunk (16 columns of the 512), and for every chunk the SIX INPUT tiles x[l + (i - 1) d] of the block's 64 group rows are
+// fetched once (the same bytes as six transformed tiles) by LDS-DMA with per-lane row addresses -- the gather the pre-pass
+// did: phase carries, frame groups, rows outside an utterance read as zero through out-of-range offsets -- and stay in LDS for
+// the six products of that chunk; a product's A fragment is then 3 - 4 ds_read_b128 of input fragments combined in registers
+// (U0 = 4 x0 - 5 x2 + x4, ...: the arithmetic of wino4_prepass_kernel) under the MFMAs of the other half step.  No U planes
+// (0.63 GB of workspace and 1.26 GB of traffic per layer at config 2), no pre-pass launch.  The conditioning part follows as
+// in wino4_fused_kernel (mel planes by DMA).  4 waves, 64 x 128 tile per product, two blocks per CU; LDS: two stages of six
+// input tiles (48 KB; the conditioning part reuses them as its operand ring) + three weight tiles (24 KB).
+struct WinoFused2Args {
+    const float* x;                                           // residual stream [32 PR][512]
+    const float* G;   long long gplane;                       // tap combinations [6][1024][512]
+    const float* mel; long long mplane; int ldm;              // conditioning operand planes (row stride ldm); plane p - pofs
+    const float* V;   long long vplane, strideVp; int ldv;    // conditioning weights: V + phase * strideVp + (p - pofs) * vplane
+    int pofs;
+    unsigned long long cfg_lo, cfg_hi; // conditioning chunks per product (see WinoFusedArgs)
+    const float* bias;
+    float* acts;
+    int Mq, phase_rows, kind, d, PR, BT, T;
+};
+
+__global__ __launch_bounds__(256, 2) void wino4_fused2_kernel(const WinoFused2Args g) {
+    constexpr int BM = 64, BN = 128, NBUF = 3, NG = C / 16;                 // NG = 32 chunks of the tap part
+    constexpr int XT = BM * 16, XS = 6 * XT, BS = BN * 16;                  // floats: one input tile, one stage of six, one weight tile
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const xs = smem;                                                 // [2][6][64][16]; conditioning part: operand ring [3][64][16]
+    float* const Bs = smem + 2 * XS;                                        // [3][128][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    constexpr int numNt = 2 * C / BN;
+    const int numMt = g.Mq / BM;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int mt = (slot / numNt) * 8 + xcd, nt = slot % numNt;
+    if (mt >= numMt) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int ph = m0 / g.phase_rows, fr0 = m0 - ph * g.phase_rows;
+
+    f32x16 acc[6][2];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][h][r] = 0.f;
+
+    // ---- per-lane source offsets.  A DMA piece = 16 rows x 64 B; lane l fetches chunk (l & 3) ^ ((l >> 4) & 3) of row l >> 2.
+    const int prow = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const int sfr = g.d / NPH;
+    // input i of this lane's group row = (block-uniform row delta of input i) + (this lane's base row), or nothing: one base
+    // offset and a validity mask per lane, the deltas go into the descriptor base
+    unsigned xbase = 0, xvalid = 0;
+    int xdelta[6];                                                          // (floats; < 2^31: checked at launch)
+    {
+        const int gl = fr0 + wave * 16 + prow;                              // group row inside the (group) phase block
+        int b = 0, t0 = 0;
+        bool ok;
+        if (g.kind == 0) {                                                  // four phases of one frame: base = the frame row
+            ok = gl < g.BT;
+            t0 = gl % g.T;
+            xbase = (unsigned)gl;
+        } else if (g.kind == 1) {                                           // four frames of one phase: base = frame t0 of the utterance
+            ok = frame_group(gl, sfr, g.BT, g.T, b, t0);
+            xbase = (unsigned)(b * g.T + t0);
+        } else {                                                            // two phases x two frames
+            ok = mixed_group(gl, g.BT, g.T, b, t0);
+            xbase = (unsigned)(b * g.T + t0);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int dt;                                                         // frame offset of input i from the base row
+            if (g.kind == 0) {
+                const int ps = group_phase0(ph, g.d) + (i - 1) * g.d;
+                dt = ps >> 5;
+                xdelta[i] = ((ps & 31) * g.PR + dt) * C;
+            } else if (g.kind == 1) {
+                dt = (i - 1) * sfr;
+                xdelta[i] = (ph * g.PR + dt) * C;
+            } else {
+                const int ps = ph + 16 * (i - 1);
+                dt = ps >> 5;
+                xdelta[i] = ((ps & 31) * g.PR + dt) * C;
+            }
+            if (ok && t0 + dt >= 0 && t0 + dt < g.T) xvalid |= 1u << i;
+        }
+        xbase = xbase * (unsigned)(C * 4) + (unsigned)chunk * 16u;
+    }
+    // this wave's two weight pieces are 16 rows apart: one per-lane offset, the second piece's distance is a scalar
+    const unsigned vb0 = (unsigned)(((2 * wave * 16 + prow) * C + chunk * 4) * 4);
+    const unsigned vb1 = (unsigned)(((2 * wave * 16 + prow) * g.ldv + chunk * 4) * 4);
+    const unsigned va1 = (unsigned)(((wave * 16 + prow) * g.ldm + chunk * 4) * 4);      // its piece of a mel-plane tile
+
+    const unsigned long long cfg_lo = g.cfg_lo, cfg_hi = g.cfg_hi;
+    auto cfg_of = [&](int p) -> unsigned {
+        return (unsigned)((p < 4 ? cfg_lo >> (16 * (p & 3)) : cfg_hi >> (16 * (p & 3))) & 0xffffull);
+    };
+    auto nchunks = [&](int p) -> int {
+        const unsigned c = cfg_of(p);
+        return (int)(c & 31) + (int)((c >> 9) & 7);
+    };
+
+    // ---- DMA requests
+    const float* const gb0 = g.G + (long long)n0 * C;
+    auto issue_x = [&](auto ic, int grp) {                                  // input tile I of chunk group `grp` -> stage grp & 1
+        constexpr int I = decltype(ic)::value;
+        const unsigned voff = (grp < NG && ((xvalid >> I) & 1u)) ? xbase : OOB;      // (past the last group: fetch nothing, keep the counts)
+        const float* base = g.x + (long long)xdelta[I];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc_uniform(base), (lds_ptr_t)(xs + (grp & 1) * XS + I * XT + wave * 256), 16, voff,
+                                                 (unsigned)grp * 64u, 0, 0);
+    };
+    auto issue_b_taps = [&](int j, int prod, int grp, int buf) {            // weight piece j of (product, chunk group) -> Bs[buf]
+        const float* base = gb0 + prod * (2 * C * C);                       // (the planes of G are 1024 x 512 floats apart)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc_uniform(base), (lds_ptr_t)(Bs + buf * BS + (2 * wave + j) * 256), 16, vb0,
+                                                 (unsigned)grp * 64u + (unsigned)j * (16u * C * 4u), 0, 0);
+    };
+    // conditioning part: (product, chunk) iterator over the products that carry chunks
+    int lp = 0, lkc = 0;
+    while (lp < 6 && nchunks(lp) == 0) ++lp;
+    const float *cab = nullptr, *cbb = nullptr;
+    auto cond_setup = [&]() {
+        cab = g.mel + (lp - g.pofs) * g.mplane + (long long)fr0 * g.ldm;
+        cbb = g.V + ph * g.strideVp + (lp - g.pofs) * g.vplane + (long long)n0 * g.ldv;
+    };
+    cond_setup();
+    bool clive = false;                                                     // the prepared conditioning tile exists
+    unsigned cka = 0, ckb = 0;
+    const float *ca = nullptr, *cb = nullptr;
+    auto cond_prepare = [&]() {                                             // address math of the next conditioning tile
+        clive = lp < 6;
+        const unsigned c = cfg_of(lp < 6 ? lp : 5);
+        const int n1 = c & 31, b1 = (c >> 5) & 15, n2 = (c >> 9) & 7, b2 = c >> 12;
+        cka = (unsigned)lkc * 64u;
+        ckb = (unsigned)(lkc < n1 ? b1 + lkc : b2 + lkc - n1) * 64u;
+        ca = cab;
+        cb = cbb;
+        if (clive && ++lkc == n1 + n2) {
+            lkc = 0;
+            ++lp;
+            while (lp < 6 && nchunks(lp) == 0) ++lp;
+            cond_setup();
+        }
+    };
+    auto cond_issue = [&](int i, int buf) {                                 // piece i (0: mel-plane rows, 1 - 2: weight rows) -> ring slot buf
+        const unsigned voff = clive ? (i == 0 ? va1 : vb1) : OOB;
+        const unsigned koff = i == 0 ? cka : ckb + (unsigned)(i - 1) * (16u * (unsigned)g.ldv * 4u);
+        const float* base = i == 0 ? ca : cb;
+        float* dst = i == 0 ? xs + buf * XT + wave * 256 : Bs + buf * BS + (2 * wave + i - 1) * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc_uniform(base), (lds_ptr_t)dst, 16, voff, koff, 0, 0);
+    };
+
+    // ---- operand fragments
+    const int xr = (li >> 2) & 3;
+    struct Frag {
+        f32x4 a, b0, b1;
+    };
+    struct Raw {
+        f32x4 v[4];
+    };
+    auto read_b = [&](int buf, int h, Frag& f) {
+        const float* b = Bs + buf * BS + (wc * 64 + li) * 16 + ((2 * h + lh) ^ xr) * 4;
+        f.b0 = *reinterpret_cast<const f32x4*>(b);
+        f.b1 = *reinterpret_cast<const f32x4*>(b + 32 * 16);
+    };
+    // product P's input fragments of half h: P = 0: x0 x2 x4, P = 1 .. 4: x1 x2 x3 x4, P = 5: x1 x3 x5
+    auto read_x = [&](auto pc, int stage, int h, Raw& r) {
+        constexpr int P = decltype(pc)::value;
+        const float* a = xs + stage * XS + (wr * 32 + li) * 16 + ((2 * h + lh) ^ xr) * 4;
+        constexpr int i0 = P == 0 ? 0 : 1, i1 = P == 0 ? 2 : P == 5 ? 3 : 2, i2 = P == 0 ? 4 : P == 5 ? 5 : 3;
+        r.v[0] = *reinterpret_cast<const f32x4*>(a + i0 * XT);
+        r.v[1] = *reinterpret_cast<const f32x4*>(a + i1 * XT);
+        r.v[2] = *reinterpret_cast<const f32x4*>(a + i2 * XT);
+        if constexpr (P >= 1 && P <= 4) r.v[3] = *reinterpret_cast<const f32x4*>(a + 4 * XT);
+    };
+    auto combine = [&](auto pc, const Raw& r) -> f32x4 {                    // the input transform (wino4_prepass_kernel)
+        constexpr int P = decltype(pc)::value;
+        if constexpr (P == 0) return 4.f * r.v[0] - 5.f * r.v[1] + r.v[2];
+        else if constexpr (P == 1) return -4.f * (r.v[0] + r.v[1]) + r.v[2] + r.v[3];
+        else if constexpr (P == 2) return 4.f * (r.v[0] - r.v[1]) - r.v[2] + r.v[3];
+        else if constexpr (P == 3) return 2.f * (r.v[2] - r.v[0]) - r.v[1] + r.v[3];
+        else if constexpr (P == 4) return 2.f * (r.v[0] - r.v[2]) - r.v[1] + r.v[3];
+        else return 4.f * r.v[0] - 5.f * r.v[1] + r.v[2];
+    };
+    auto mfma2 = [&](auto pc, const Frag& f, int kk) {
+        constexpr int P = decltype(pc)::value;
+        acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk], f.b0[kk], acc[P][0], 0, 0, 0);
+        acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk], f.b1[kk], acc[P][1], 0, 0, 0);
+    };
+
+    // ---- prologue: the six input tiles of group 0, weight tiles 0 and 1, the first third of group 1, weight tile 2 (the order the
+    // steady state leaves behind: tile t + 1's pieces are the last requests of step t - 2)
+    static_for<6>([&](auto ic) { issue_x(ic, 0); });
+    issue_b_taps(0, 0, 0, 0); issue_b_taps(1, 0, 0, 0);
+    issue_b_taps(0, 1, 0, 1); issue_b_taps(1, 1, 0, 1);
+    issue_x(std::integral_constant<int, 0>{}, 1); issue_x(std::integral_constant<int, 1>{}, 1);
+    issue_b_taps(0, 2, 0, 2); issue_b_taps(1, 2, 0, 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+    Raw raw;
+    read_x(std::integral_constant<int, 0>{}, 0, 0, raw);
+    read_b(0, 0, f0);
+    f0.a = combine(std::integral_constant<int, 0>{}, raw);
+
+    // ---- tap part: 32 chunk groups x 6 products, rotated by half a step.  Step (grp, P) = [input fragments of the second half |
+    // MFMAs of the first | wait, barrier | fragments of the next tile's first half | MFMAs of the second half with this step's
+    // requests: P = 5 / 0 / 1: two input tiles of a coming group; always: the weight tile three steps ahead]
+    int buf = 0;                                                            // weight-ring slot of the current tile
+    for (int grp = 0; grp < NG; ++grp) {
+        const int stage = grp & 1;
+        static_for<6>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            constexpr int PN = (P + 1) % 6;
+            // half-step = [input fragments of the next half | 2 MFMA pairs | combine | weight fragments | 2 MFMA pairs]: the sixteen
+            // input registers and the eight weight registers of the incoming half are never live together (register budget)
+            read_x(pc, stage, 1, raw);
+            mfma2(pc, f0, 0);
+            mfma2(pc, f0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f1.a = combine(pc, raw);
+            read_b(buf, 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(pc, f0, 2);
+            mfma2(pc, f0, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            // requests of the previous step that may stay in flight: its two weight pieces (+ two input pieces after P = 5, 0, 1)
+            if constexpr (P <= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int bufn = buf == NBUF - 1 ? 0 : buf + 1;
+            const bool last = P == 5 && grp == NG - 1;                      // the next tile is the first conditioning tile
+            if (!last) read_x(std::integral_constant<int, PN>{}, P == 5 ? stage ^ 1 : stage, 0, raw);
+            // the tile three steps ahead: product (P + 3) % 6 of this group or the next, or a conditioning tile
+            const int g3 = grp + (P >= 3 ? 1 : 0);
+            constexpr int P3 = (P + 3) % 6;
+            const bool cond3 = g3 >= NG;
+            if (cond3) cond_prepare();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(pc, f1, 0);
+            if constexpr (P == 5) issue_x(std::integral_constant<int, 0>{}, grp + 2);
+            if constexpr (P == 0) issue_x(std::integral_constant<int, 2>{}, grp + 1);
+            if constexpr (P == 1) issue_x(std::integral_constant<int, 4>{}, grp + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(pc, f1, 1);
+            if constexpr (P == 5) issue_x(std::integral_constant<int, 1>{}, grp + 2);
+            if constexpr (P == 0) issue_x(std::integral_constant<int, 3>{}, grp + 1);
+            if constexpr (P == 1) issue_x(std::integral_constant<int, 5>{}, grp + 1);
+            if (cond3) cond_issue(0, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (last) f0.a = *reinterpret_cast<const f32x4*>(xs + bufn * XT + (wr * 32 + li) * 16 + (lh ^ xr) * 4);
+            else f0.a = combine(std::integral_constant<int, PN>{}, raw);
+            read_b(bufn, 0, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(pc, f1, 2);
+            if (cond3) cond_issue(1, buf);
+            else issue_b_taps(0, P3, g3, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma2(pc, f1, 3);
+            if (cond3) cond_issue(2, buf);
+            else issue_b_taps(1, P3, g3, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            buf = bufn;
+        });
+    }
+    // ---- conditioning part (as wino4_fused_kernel): operand ring in the first input stage, three pieces per wave and tile
+    static_for<6>([&](auto pc) {
+        const int nsteps = nchunks(decltype(pc)::value);
+        for (int s = 0; s < nsteps; ++s) {
+            {
+                const float* a = xs + buf * XT + (wr * 32 + li) * 16 + ((2 + lh) ^ xr) * 4;
+                f1.a = *reinterpret_cast<const f32x4*>(a);
+            }
+            read_b(buf, 1, f1);
+            cond_prepare();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) mfma2(pc, f0, kk);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int bufn = buf == NBUF - 1 ? 0 : buf + 1;
+            {
+                const float* a = xs + bufn * XT + (wr * 32 + li) * 16 + (lh ^ xr) * 4;
+                f0.a = *reinterpret_cast<const f32x4*>(a);
+            }
+            read_b(bufn, 0, f0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                mfma2(pc, f1, kk);
+                if (kk < 3) {
+                    cond_issue(kk, buf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            buf = bufn;
+        }
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue (as wino4_fused_kernel)
+    float* patch = smem + wave * (32 * 36);
+    const int er = lane >> 3, ec4 = (lane & 7) * 4;
+    const float bt = g.bias[n0 + wc * 64 + li], bs = g.bias[n0 + wc * 64 + 32 + li];
+    const int ch0 = ((n0 + wc * 64) >> 6) * 32 + ec4;
+    auto out_row = [&](int lr, int j) -> long long {
+        const int gl = fr0 + lr;
+        if (g.kind == 0) return (long long)(group_phase0(ph, g.d) + j * g.d) * g.PR + gl;
+        int b, t0;
+        if (g.kind == 1) {
+            if (!frame_group(gl, sfr, g.BT, g.T, b, t0) || t0 + j * sfr >= g.T) return -1;
+            return (long long)ph * g.PR + (long long)b * g.T + t0 + j * sfr;
+        }
+        if (!mixed_group(gl, g.BT, g.T, b, t0) || t0 + (j >> 1) >= g.T) return -1;
+        return (long long)(ph + 16 * (j & 1)) * g.PR + (long long)b * g.T + t0 + (j >> 1);
+    };
+    static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float tv, sv;
+            if constexpr (j == 0) {
+                tv = acc[0][0][r] + acc[1][0][r] + acc[2][0][r] + acc[3][0][r] + acc[4][0][r] + bt;
+                sv = acc[0][1][r] + acc[1][1][r] + acc[2][1][r] + acc[3][1][r] + acc[4][1][r] + bs;
+            } else if constexpr (j == 1) {
+                tv = acc[1][0][r] - acc[2][0][r] + 2.f * (acc[3][0][r] - acc[4][0][r]) + bt;
+                sv = acc[1][1][r] - acc[2][1][r] + 2.f * (acc[3][1][r] - acc[4][1][r]) + bs;
+            } else if constexpr (j == 2) {
+                tv = acc[1][0][r] + acc[2][0][r] + 4.f * (acc[3][0][r] + acc[4][0][r]) + bt;
+                sv = acc[1][1][r] + acc[2][1][r] + 4.f * (acc[3][1][r] + acc[4][1][r]) + bs;
+            } else {
+                tv = acc[1][0][r] - acc[2][0][r] + 8.f * (acc[3][0][r] - acc[4][0][r]) + acc[5][0][r] + bt;
+                sv = acc[1][1][r] - acc[2][1][r] + 8.f * (acc[3][1][r] - acc[4][1][r]) + acc[5][1][r] + bs;
+            }
+            patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = gate_tanh_sigmoid(tv, sv);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(patch + (er + 8 * qq) * 36 + ec4);
+            const long long row = out_row(wr * 32 + er + 8 * qq, j);
+            if (row >= 0) *reinterpret_cast<f32x4*>(g.acts + row * C + ch0) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+}
+
+hipError_t launch_wino_fused2(const WinoFused2Args& a, hipStream_t st) {
+    constexpr int BM = 64, BN = 128;
+    const size_t lds = (size_t)(2 * 6 * BM * 16 + 3 * BN * 16) * sizeof(float);
+    if (a.Mq % BM != 0 || a.phase_rows % BM != 0 || a.Mq % a.phase_rows != 0) return hipErrorInvalidValue;
+    static PerDeviceOnce attr_set;
+    if (hipError_t e = set_max_dyn_lds_once((const void*)wino4_fused2_kernel, lds, attr_set); e != hipSuccess) return e;
+    const int numMt8 = (a.Mq / BM + 7) / 8 * 8;
+    hipLaunchKernelGGL(wino4_fused2_kernel, dim3(numMt8 * (2 * C / BN)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
@@ -690,7 +1051,8 @@ struct MelPlanes {
 };
 
 // Workspace and the mel planes of one call (the mel does not change across layers and flows)
-int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T, bool three_pass) {
+int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, int T, int form) {
+    const bool three_pass = form == 2, need_U = form != 1;                 // form 1 transforms its inputs on the fly: no U planes
     WaveGlowDev& wg = e->wg;
     hipStream_t st = e->stream;
     const int PRq = frame_group_rows(BT, T), PRm = mixed_group_rows(BT, T);
@@ -705,7 +1067,7 @@ int waveglow_wino_begin(tts_hip_engine* e, const float* d_mel, int PR, int BT, i
                        bytes, hipGetErrorString(err));
     };
     int rc;
-    if ((rc = room(wg.wino_U, rows * C * 4))) return rc;
+    if (need_U && (rc = room(wg.wino_U, rows * C * 4))) return rc;
     if (three_pass && (rc = room(wg.wino_P, rows * 2 * C * 4))) return rc;
     if ((rc = room(wg.wino_mel, mp.total * 4))) return rc;
     float* base = wg.wino_mel.f();
@@ -730,7 +1092,8 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
     const int PRq = frame_group_rows(BT, T), PRm = mixed_group_rows(BT, T);
     const bool phases = d <= 8, mixed = d == 16;
     const long long Mq = phases ? (long long)(NPH / 4) * PR : mixed ? (long long)16 * PRm : (long long)NPH * PRq;
-    hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
+    const bool no_prepass = wg.form_mode == 1;             // form 1 (default): input transform inside the GEMM's operand reads
+    if (!no_prepass) hipLaunchKernelGGL(wino4_prepass_kernel, dim3(blocks_for(Mq * (C / 4))), dim3(256), 0, st, x, U, d, PR, BT, T, Mq);
     if (wg.form_mode != 2) {                               // fused GEMM + output transform + gate (form 2: the three passes)
         WinoFusedArgs a{};
         a.U = U;
@@ -780,15 +1143,25 @@ int waveglow_wino_layer(tts_hip_engine* e, const WgLayerDev& ly, int i, const fl
             ccfg[3] = ccfg[4] = cc((SB + SC) / 16, SA / 16);                   // [B | C]
         }
         for (int p = 0; p < 6; ++p) (p < 4 ? a.cfg_lo : a.cfg_hi) |= (unsigned long long)ccfg[p] << (16 * (p & 3));
-        timing_begin(e, 0);
-        switch (wg.form_mode) {                            // forms >= 3: tile / pipeline variants kept for measurement
-            case 3: HIPCHK(e, (launch_wino_fused<2, 2, 4, 2>(a, st))); break;
-            case 4: HIPCHK(e, (launch_wino_fused<4, 1, 3, 2>(a, st))); break;
-            case 5: HIPCHK(e, (launch_wino_fused<4, 2, 3, 1>(a, st))); break;
-            case 6: HIPCHK(e, (launch_wino_fused<4, 2, 6, 1>(a, st))); break;
-            case 7: HIPCHK(e, (launch_wino_fused<2, 2, 6, 2>(a, st))); break;
-            default: HIPCHK(e, (launch_wino_fused<2, 2, 3, 2>(a, st))); break;
+        if (no_prepass) {
+            WinoFused2Args b{};
+            b.x = x;
+            b.G = a.G; b.gplane = a.gplane;
+            b.mel = a.mel; b.mplane = a.mplane; b.ldm = a.ldm;
+            b.V = a.V; b.vplane = a.vplane; b.strideVp = a.strideVp; b.ldv = a.ldv;
+            b.pofs = a.pofs;
+            b.cfg_lo = a.cfg_lo; b.cfg_hi = a.cfg_hi;
+            b.bias = a.bias; b.acts = a.acts;
+            b.Mq = a.Mq; b.phase_rows = a.phase_rows; b.kind = a.kind; b.d = a.d; b.PR = a.PR; b.BT = a.BT; b.T = a.T;
+            timing_begin(e, 0);
+            HIPCHK(e, launch_wino_fused2(b, st));
+            timing_end(e);
+            return TTS_HIP_OK;
         }
+        timing_begin(e, 0);
+        // form 3 (measurement): the fused kernel behind the pre-pass (64 x 128 tiles, two blocks per CU; measured at config 2
+        // on one box: three passes 433 ms per step, this 415, without the pre-pass 409; 8-wave 128 x 128 blocks: 425)
+        HIPCHK(e, (launch_wino_fused<2, 2, 3, 2>(a, st)));
         timing_end(e);
         return TTS_HIP_OK;
     }
