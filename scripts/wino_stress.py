@@ -1,6 +1,7 @@
 """Random call shapes through the fp32 vocoder in both forms of the WN convolutions (Winograd F(4,3) vs direct) on the same
 inputs: batch 1 - 12, 30 - 900 frames per utterance (partial frame groups, padded phase blocks, 128- and 256-row tiles), noise
-given or not.  HIP against HIP: the two forms must agree within fp32 rounding on every shape; which form ran is reported."""
+given or not.  HIP against HIP: the two forms must agree within fp32 rounding on every shape, and the one-kernel Winograd form must EQUAL the
+three-pass form of round 3; which form ran is reported."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,12 +22,14 @@ for it in range(n):
     mel = torch.from_numpy(rng.uniform(-11.5, 1.2, (B, T, 80)).astype(np.float32)).cuda()
     z = torch.from_numpy(rng.standard_normal((B, T * 32, 8)).astype(np.float32)).cuda() if it % 4 else None
     outs = {}
-    for form in ('winograd', 'direct'):
+    for form in ('winograd', 'direct', 'winograd-3pass'):
         eng.set_waveglow_form(form)
         outs[form] = eng.waveglow_infer(mel, z=z)
         if form == 'winograd':
             ran[eng.last_waveglow_form] += 1
             took = eng.last_waveglow_form
+    # round 4: the one-kernel Winograd form against round 3's three passes -- the same products in the same order: bit for bit
+    assert torch.equal(outs['winograd'], outs['winograd-3pass']), (B, T, 'fused kernel differs from the three passes')
     assert bool(torch.isfinite(outs['winograd']).all()) and outs['winograd'].shape == (B, T * 256)
     d = float(torch.sqrt(torch.mean((outs['winograd'] - outs['direct']) ** 2)))
     m = float((outs['winograd'] - outs['direct']).abs().max())

@@ -187,6 +187,30 @@ def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_we
         gpu_engine.set_waveglow_form('fft')
 
 
+def test_winograd_kernel_is_bit_identical_to_its_three_pass_form(gpu_engine):
+    """The default Winograd form is ONE kernel per layer (input transform in the operand reads, six accumulator sets, output
+    transform + gate in the epilogue; csrc/wn_wino.hip); round 3's three passes (pre-pass, per-product GEMM, combine) and the
+    intermediate stage (fused GEMM behind the pre-pass) are kept as measurement forms.  All three form the same products in
+    the same k order and write the transforms identically, so their waveforms are EQUAL bit for bit -- which makes this a
+    sharp test of the fused kernel's LDS-DMA pipeline (a tile read before it landed shows up as a difference, and as a
+    difference between two runs): two runs of each shape, shapes with partial frame groups and padded group rows."""
+    try:
+        for B, T, seed in ((2, 200, 81), (3, 131, 82), (1, 513, 83)):
+            mel, z = _inputs(B, T, seed=seed)
+            outs = {}
+            for form in ('winograd-3pass', 'winograd-prepass', 'winograd', 'winograd'):
+                gpu_engine.set_waveglow_form(form)
+                out = gpu_engine.waveglow_infer(mel, z=z)
+                assert gpu_engine.last_waveglow_form == 'winograd' and np.isfinite(out).all()
+                if form in outs:
+                    assert np.array_equal(out, outs[form]), f'{B} x {T}: two runs of the fused kernel differ'
+                outs[form] = out
+            assert np.array_equal(outs['winograd'], outs['winograd-3pass']), f'{B} x {T}: fused kernel vs three passes'
+            assert np.array_equal(outs['winograd-prepass'], outs['winograd-3pass']), f'{B} x {T}: fused GEMM behind the pre-pass'
+    finally:
+        gpu_engine.set_waveglow_form('winograd')
+
+
 def test_waveglow_winograd_form_with_four_times_less_end_attenuation(wg_cfg):
     """The Winograd form where the session weights' 0.05 `end` scaling does not damp it 20x: `end_scale` = 0.2 (signal RMS
     ~2.6, the largest scale at which a random-weight flow is a well-conditioned map) on 2 x 200 frames

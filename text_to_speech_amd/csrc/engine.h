@@ -73,7 +73,7 @@ struct WaveGlowDev {
     float* probe_out = nullptr;              //   its gated activations to this device buffer [B][T * 32][512]
     bool wino_ready = false;                 // Winograd form of the fp32 in-layer GEMM (wn_wino.hip)
     bool wino_legacy_ready = false;          //   ... and the three-pass form's extra weight copies
-    DevBuf wino_U, wino_P, wino_mel;         // transformed inputs [4][M/2][512], products [4][M/2][1024], mel planes
+    DevBuf wino_U, wino_P, wino_mel;         // mel planes; forms 2 / 3 only: transformed inputs [6][M/4][512], products [6][M/4][1024]
 };
 
 // ---------------------------------------------------------------- Tacotron2

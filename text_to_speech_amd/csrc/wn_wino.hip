@@ -1,33 +1,49 @@
-// wn_wino.hip -- Winograd minimal filtering F(4,3) along the tap axis of the WN dilated convolution (fp32 path, 128- / 256-row tiles).
+// wn_wino.hip -- Winograd minimal filtering F(4,3) along the tap axis of the WN dilated convolution (fp32 path, calls of 384
+// frames or more).
 //
 // The in-layer pre-activation of WaveGlow's WN (/root/reference/architectures/waveglow_arch.py:117-127) is a k = 3 dilated
 // convolution plus the conditioning term,  y[l] = W- x[l - d] + W0 x[l] + W+ x[l + d] + c[l] + b.  The FOUR outputs
 // y[l], y[l + d], y[l + 2d], y[l + 3d] share the six inputs x[l - d] ... x[l + 4d] and need only SIX K = 512 products
-// instead of twelve (K per output 768 instead of 1536), and the six products are ONE launch of the GEMM kernel of gemm_f32.h:
-// one blockIdx.z slice per product on M / 4 "group rows", operand planes U[z] against weight planes G[z].  Three passes per
-// layer:
+// instead of twelve (K per output 768 instead of 1536) on M / 4 "group rows":
 //
-//   pre-pass   x -> U[6][M / 4][512]           (the transformed inputs; HBM-bound)
-//   GEMM       P[z] = U[z] G[z]^T + melP[z] V[z]^T
-//   combine    y_j = sum_z AT[j][z] P[z] + b,  acts = tanh(.) * sigmoid(.)  written to the four output rows
+//   input transform    U_p = sum_i BT[p][i] x_i                      (six combinations of the six inputs)
+//   products           P_p = U_p G_p^T + melP_p V_p^T                (G: tap combinations, built at load)
+//   output transform   y_j = sum_p AT[j][p] P_p + b,  acts = tanh(.) * sigmoid(.)  written to the four output rows
+//
+// Round 4: ONE kernel per layer (wino4_fused2_kernel, the default form).  A block owns 64 group rows x 128 pre-activation
+// columns of ALL SIX products (a wave: 32 x 64 x 6 = 192 accumulator registers).  Its K loop walks the 512 tap columns chunk by
+// chunk: the six INPUT tiles of a chunk arrive by LDS-DMA with per-lane row addresses (phase carries, frame groups, zeros
+// outside an utterance through out-of-range offsets), a product's A fragment is three or four input fragments combined in
+// registers under the other half step's MFMAs, and the epilogue applies the output transform, bias and gate in registers:
+// no U planes, no P planes, no pre-pass or combine launch.  Measured at config 2 on one box: three passes (round 3) 433 ms
+// per step, fused GEMM behind the pre-pass 415, this 409 (direct form 565); the kernel runs the 464 GFLOP a layer executes in
+// 3.72 ms (79 % of the fp32 MFMA peak INCLUDING both transforms and the gate; the per-product GEMM of round 3 alone ran at
+// 85 %, its layer -- 0.19 + 3.55 + 0.27 ms -- at 74 %).  What bounds the tile: six accumulator sets leave room for 64 x 128
+// per four waves at two blocks per CU (8-wave 128 x 128 blocks measured 3 % slower: one barrier domain per CU and 12.5
+// rounds of 256 blocks), i.e. 12 DMA pieces per 16 MFMAs and wave -- twice the direct kernel's bytes per MFMA.
+// Forms 2 and 3 (tts_hip_set_waveglow_form; measurement only, bit-identical results) keep the earlier stages: the three
+// passes (wino4_prepass_kernel, one z slice of gemm_f32_kernel per product, wino4_combine_kernel) and the fused GEMM behind
+// the pre-pass (wino4_fused_kernel).
 //
 // The conditioning term (K = 320 per output) is spread over the products so that none idles: three K slices A = [0, 112),
 // B = [112, 208), C = [208, 320), each carried by a product subset whose columns of the output transform AT have rank 4 --
-// {0, 1, 2, 5}, {0, 3, 4, 5}, {1, 2, 3, 4} -- and combined with the inverse of those columns: K = 512 + 224 per product (208
-// padded to 224 for products 0, 3, 4, 5).
+// {0, 1, 2, 5}, {0, 3, 4, 5}, {1, 2, 3, 4} -- and combined with the inverse of those columns: K = 512 + 208 for products
+// 0, 3, 4, 5 and 512 + 224 for products 1, 2 (the fused kernels skip the all-zero padding chunk of the 208-column products).
 //
 // Groups.  Dilation d <= 8 (sample groups): four PHASES p0 + j d of one frame, 8 group phases p0 = (gp / d) 4d + gp % d; the
 // outputs share their mel rows and differ in the per-phase conditioning weights, so the slice combinations are WEIGHT
 // combinations built at load.  d >= 32 (s = d / 32 frames): four FRAMES t0 + j s of one phase; the outputs share the weights
-// and the combinations are MEL combinations built once per call.  d = 16: two phases x two frames, sharing neither -- but
-// every row of subset {1, 2, 3, 4}'s coefficient matrix is an outer product (over the two frames) x (over the two phases),
-// so those four products carry the WHOLE conditioning as one mel combination times one weight combination each (K = 512 +
-// 320, first launch) and products 0 and 5 run K = 512 (second launch): the same K per output.  Frame groups are cut per
-// utterance, so any utterance length works.
+// -- the products' weights are chunk ranges of cond_Bt itself, no copies (round 3 kept six column-selected copies per phase:
+// 6.3 GB) -- and the combinations are MEL combinations built once per call.  d = 16: two phases x two frames, sharing neither
+// -- but every row of subset {1, 2, 3, 4}'s coefficient matrix is an outer product (over the two frames) x (over the two
+// phases), so those four products carry the WHOLE conditioning as one mel combination times one weight combination each
+// (K = 512 + 320) and products 0 and 5 run K = 512: the same K per output.  Frame groups are cut per utterance, so any
+// utterance length works.
 //
 // Numerics: every operand stays fp32, weight / mel combinations are formed in fp64 and rounded once.  F(4,3)'s transform
-// constants (4, 5, 8, 1/6, 1/24) cost accuracy: error of one layer ~3x the direct form's; end to end against the oracle
-// 6.0e-7 waveform RMS (direct form 4.96e-7; tolerance 1e-4).  Not bit-identical to the direct form.
+// constants (4, 5, 8, 1/6, 1/24) cost accuracy: one layer's gated activations against the oracle 1.9e-6 relative RMS (direct
+// form 1.4e-6; tests/test_waveglow_gpu.py), end to end 6.0e-7 waveform RMS (direct form 4.96e-7; tolerance 1e-4), with four
+// times less `end` attenuation 6.5e-6 (4.9e-6).  Not bit-identical to the direct form.
 #include "engine.h"
 #include "gemm_f32.h"
 
@@ -804,14 +820,16 @@ __global__ __launch_bounds__(256, 2) void wino4_fused2_kernel(const WinoFused2Ar
         acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk], f.b1[kk], acc[P][1], 0, 0, 0);
     };
 
-    // ---- prologue: the six input tiles of group 0, weight tiles 0 and 1, the first third of group 1, weight tile 2 (the order the
-    // steady state leaves behind: tile t + 1's pieces are the last requests of step t - 2)
-    static_for<6>([&](auto ic) { issue_x(ic, 0); });
+    // ---- prologue: the six input tiles of group 0 and weight tiles 0 - 2.  Steady state: every step requests ONE input tile
+    // of the next group (in the order the products need them: x0 x2 x4 | x1 x3 | x5) and the weight tile three steps ahead -- three
+    // pieces per wave and step, so "all but the last three requests" = everything up to two steps ago = the next tile's operands.
+    // (the prologue ends like a steady-state step: [one input tile, weight tile 2], so that step 0's "all but three" covers tile 1)
+    static_for<5>([&](auto ic) { issue_x(ic, 0); });
     issue_b_taps(0, 0, 0, 0); issue_b_taps(1, 0, 0, 0);
     issue_b_taps(0, 1, 0, 1); issue_b_taps(1, 1, 0, 1);
-    issue_x(std::integral_constant<int, 0>{}, 1); issue_x(std::integral_constant<int, 1>{}, 1);
+    issue_x(std::integral_constant<int, 5>{}, 0);
     issue_b_taps(0, 2, 0, 2); issue_b_taps(1, 2, 0, 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     Frag f0, f1;
     Raw raw;
@@ -821,13 +839,18 @@ __global__ __launch_bounds__(256, 2) void wino4_fused2_kernel(const WinoFused2Ar
 
     // ---- tap part: 32 chunk groups x 6 products, rotated by half a step.  Step (grp, P) = [input fragments of the second half |
     // MFMAs of the first | wait, barrier | fragments of the next tile's first half | MFMAs of the second half with this step's
-    // requests: P = 5 / 0 / 1: two input tiles of a coming group; always: the weight tile three steps ahead]
+    // three requests].  The last group (its look-ahead reaches the conditioning tiles) is a second copy of the body, so that
+    // neither copy branches.
     int buf = 0;                                                            // weight-ring slot of the current tile
-    for (int grp = 0; grp < NG; ++grp) {
+    auto group_body = [&](int grp, auto lastc) {
+        constexpr bool LASTG = decltype(lastc)::value;
         const int stage = grp & 1;
         static_for<6>([&](auto pc) {
             constexpr int P = decltype(pc)::value;
-            constexpr int PN = (P + 1) % 6;
+            constexpr int PN = (P + 1) % 6, P3 = (P + 3) % 6;
+            constexpr int XI = P < 3 ? 2 * P : P == 3 ? 1 : P == 4 ? 3 : 5;  // the input tile of the next group requested in this step
+            constexpr bool COND3 = LASTG && P >= 3;                         // the tile three steps ahead is a conditioning tile
+            constexpr bool LAST = LASTG && P == 5;                          // the next tile is the first conditioning tile
             // half-step = [input fragments of the next half | 2 MFMA pairs | combine | weight fragments | 2 MFMA pairs]: the sixteen
             // input registers and the eight weight registers of the incoming half are never live together (register budget)
             read_x(pc, stage, 1, raw);
@@ -840,45 +863,35 @@ __global__ __launch_bounds__(256, 2) void wino4_fused2_kernel(const WinoFused2Ar
             mfma2(pc, f0, 2);
             mfma2(pc, f0, 3);
             __builtin_amdgcn_sched_barrier(0);
-            // requests of the previous step that may stay in flight: its two weight pieces (+ two input pieces after P = 5, 0, 1)
-            if constexpr (P <= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const int bufn = buf == NBUF - 1 ? 0 : buf + 1;
-            const bool last = P == 5 && grp == NG - 1;                      // the next tile is the first conditioning tile
-            if (!last) read_x(std::integral_constant<int, PN>{}, P == 5 ? stage ^ 1 : stage, 0, raw);
-            // the tile three steps ahead: product (P + 3) % 6 of this group or the next, or a conditioning tile
-            const int g3 = grp + (P >= 3 ? 1 : 0);
-            constexpr int P3 = (P + 3) % 6;
-            const bool cond3 = g3 >= NG;
-            if (cond3) cond_prepare();
+            if constexpr (!LAST) read_x(std::integral_constant<int, PN>{}, P == 5 ? stage ^ 1 : stage, 0, raw);
+            if constexpr (COND3) cond_prepare();
             __builtin_amdgcn_sched_barrier(0);
             mfma2(pc, f1, 0);
-            if constexpr (P == 5) issue_x(std::integral_constant<int, 0>{}, grp + 2);
-            if constexpr (P == 0) issue_x(std::integral_constant<int, 2>{}, grp + 1);
-            if constexpr (P == 1) issue_x(std::integral_constant<int, 4>{}, grp + 1);
+            if constexpr (COND3) cond_issue(0, buf);
+            else issue_x(std::integral_constant<int, XI>{}, grp + 1);       // (last group: fetches nothing, keeps the counts)
             __builtin_amdgcn_sched_barrier(0);
             mfma2(pc, f1, 1);
-            if constexpr (P == 5) issue_x(std::integral_constant<int, 1>{}, grp + 2);
-            if constexpr (P == 0) issue_x(std::integral_constant<int, 3>{}, grp + 1);
-            if constexpr (P == 1) issue_x(std::integral_constant<int, 5>{}, grp + 1);
-            if (cond3) cond_issue(0, buf);
             __builtin_amdgcn_sched_barrier(0);
-            if (last) f0.a = *reinterpret_cast<const f32x4*>(xs + bufn * XT + (wr * 32 + li) * 16 + (lh ^ xr) * 4);
+            if constexpr (LAST) f0.a = *reinterpret_cast<const f32x4*>(xs + bufn * XT + (wr * 32 + li) * 16 + (lh ^ xr) * 4);
             else f0.a = combine(std::integral_constant<int, PN>{}, raw);
             read_b(bufn, 0, f0);
             __builtin_amdgcn_sched_barrier(0);
             mfma2(pc, f1, 2);
-            if (cond3) cond_issue(1, buf);
-            else issue_b_taps(0, P3, g3, buf);
+            if constexpr (COND3) cond_issue(1, buf);
+            else issue_b_taps(0, P3, grp + (P >= 3 ? 1 : 0), buf);
             __builtin_amdgcn_sched_barrier(0);
             mfma2(pc, f1, 3);
-            if (cond3) cond_issue(2, buf);
-            else issue_b_taps(1, P3, g3, buf);
+            if constexpr (COND3) cond_issue(2, buf);
+            else issue_b_taps(1, P3, grp + (P >= 3 ? 1 : 0), buf);
             __builtin_amdgcn_sched_barrier(0);
             buf = bufn;
         });
-    }
+    };
+    for (int grp = 0; grp < NG - 1; ++grp) group_body(grp, std::false_type{});
+    group_body(NG - 1, std::true_type{});
     // ---- conditioning part (as wino4_fused_kernel): operand ring in the first input stage, three pieces per wave and tile
     static_for<6>([&](auto pc) {
         const int nsteps = nchunks(decltype(pc)::value);
