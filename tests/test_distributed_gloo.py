@@ -28,7 +28,14 @@ def _fake_synth(tok, spk):
     return audio, n * 7
 
 
-def _worker(rank, world, port, n_utt, with_spk, ret):
+def _fake_synth_tensors(tok, spk):
+    """The same audio as torch tensors on the collective's device (what `TTSPipeline.shard_fn` returns on a GPU): they go into
+    the gather as they are."""
+    audio, counts = _fake_synth(tok, spk)
+    return torch.from_numpy(audio), torch.from_numpy(np.asarray(counts, dtype=np.int64))
+
+
+def _worker(rank, world, port, n_utt, with_spk, ret, tensors=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -39,7 +46,8 @@ def _worker(rank, world, port, n_utt, with_spk, ret):
     for i, n in enumerate(lens):
         tok[i, :n] = rng.integers(1, 148, n)
     spk = rng.standard_normal((n_utt, 4)).astype(np.float32) if with_spk else None
-    out = synthesize_sharded(tok if rank == 0 else None, _fake_synth, speaker=spk if rank == 0 else None)
+    out = synthesize_sharded(tok if rank == 0 else None, _fake_synth_tensors if tensors else _fake_synth,
+                             speaker=spk if rank == 0 else None)
     if rank == 0:
         ok = len(out) == n_utt
         for i in range(n_utt):
@@ -51,12 +59,12 @@ def _worker(rank, world, port, n_utt, with_spk, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_utt,with_spk', [(7, False), (8, True), (1, False)])
-def test_scatter_gather_roundtrip_world2(n_utt, with_spk):
+@pytest.mark.parametrize('n_utt,with_spk,tensors', [(7, False, False), (8, True, False), (1, False, False), (7, True, True), (1, False, True)])
+def test_scatter_gather_roundtrip_world2(n_utt, with_spk, tensors):
     ctx = mp.get_context('spawn')
     ret = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_utt, with_spk, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_utt, with_spk, ret, tensors)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
