@@ -55,12 +55,12 @@ def wino_in_layer_flops(B: int, T: int) -> float:
     """FLOPs the Winograd form of the in-layer GEMM EXECUTES per launch, averaged over the 7 launches of a flow (one fused
     kernel per layer, csrc/wn_wino.hip, F(4,3)): six products on M / 4 group rows -- K = 512 taps + the product's conditioning
     chunks: 208 columns for products 0, 3, 4, 5 and 224 for products 1, 2 -- for the dilations 2, 4, 8 (groups of phases) and
-    32, 64, 128 (groups of frames, group rows per phase padded to the 128-row tile); dilation 16 (two phases x two frames):
+    32, 64, 128 (groups of frames, group rows per phase padded to the 64-row tile); dilation 16 (two phases x two frames):
     four K = 512 + 320 products and two K = 512 products."""
     BT = B * T
     PR = (BT + 255) // 256 * 256                         # frame rows per phase block (256-row tiles)
-    PRq = (B * ((T + 15) // 16 * 4) + 127) // 128 * 128
-    PRm = (B * ((T + 1) // 2) + 127) // 128 * 128
+    PRq = (B * ((T + 15) // 16 * 4) + 63) // 64 * 64     # group rows per phase, padded to the fused kernel's 64-row tile
+    PRm = (B * ((T + 1) // 2) + 63) // 64 * 64
     k6 = 4 * (512 + 208) + 2 * (512 + 224)               # K summed over the six products
     phases = (8 * PR) * k6
     frames = (32 * PRq) * k6

@@ -325,7 +325,9 @@ int tts_hip_waveglow_probe_acts(tts_hip_engine* e, const float* mel, int B, int 
     const size_t n_mel = (size_t)B * T * 80, n_z = (size_t)B * T * 32 * 8, n_acts = (size_t)B * T * 32 * 512;
     const float* d_mel = mel;
     const float* d_z = z;
-    DevBuf tmp;
+    struct Scratch : DevBuf {                                   // (DevBuf has no destructor: the engine's buffers live with the handle)
+        ~Scratch() { release(); }
+    } tmp;
     if (mem == TTS_HIP_MEM_HOST) {
         HIPCHK(e, e->wg.io_mel.ensure(n_mel * 4));
         HIPCHK(e, hipMemcpyAsync(e->wg.io_mel.p, mel, n_mel * 4, hipMemcpyHostToDevice, e->stream));
@@ -347,7 +349,6 @@ int tts_hip_waveglow_probe_acts(tts_hip_engine* e, const float* mel, int B, int 
     hipError_t herr = hipSuccess;
     if (!rc && mem == TTS_HIP_MEM_HOST) herr = hipMemcpyAsync(acts, tmp.p, n_acts * 4, hipMemcpyDeviceToHost, e->stream);
     const hipError_t serr = hipStreamSynchronize(e->stream);
-    tmp.release();
     if (rc) return rc;
     HIPCHK(e, herr);
     HIPCHK(e, serr);

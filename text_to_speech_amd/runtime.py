@@ -235,7 +235,8 @@ class HipRuntime(Runtime):
         spk_dev = speaker is not None and _is_torch_cuda(speaker)
         if self._encoded is not None and self._encoded[0][0] == 'dev':
             _, kept_tok, kept_spk = self._encoded[0]
-            same = tuple(kept_tok.shape) == tuple(tokens.shape) and (kept_spk is None) == (speaker is None)
+            same = (kept_tok.device == tokens.device and tuple(kept_tok.shape) == tuple(tokens.shape)
+                    and (kept_spk is None) == (speaker is None))
             if same and speaker is not None:
                 spk = speaker if spk_dev else torch.as_tensor(np.asarray(speaker), dtype=torch.float32)
                 same = tuple(kept_spk.shape) == tuple(spk.shape) and bool(torch.equal(kept_spk, spk.to(device=kept_spk.device, dtype=torch.float32)))
