@@ -172,7 +172,7 @@ int tts_hip_set_decoder_mode(tts_hip_engine* e, int mode);
 int tts_hip_last_decoder_mode(const tts_hip_engine* e);
 
 /* How the fp32 WaveGlow path evaluates the k = 3 dilated convolution of WN layers 1 .. 7 (waveglow_arch.py:117-127).
- * form 1 (default): Winograd minimal filtering along the tap axis for calls of 384 frames or more (any utterance length;
+ * form 1 (default): Winograd minimal filtering along the tap axis for calls of 144 frames or more (any utterance length;
  * csrc/wn_wino.hip) -- F(4,3), six products per four outputs: K per output ~800 + 320 instead of 1536 + 320, fp32 operands
  * and accumulators, ONE kernel per layer (input transform in the operand reads, the six products as accumulator sets of one
  * block, output transform + gate in the epilogue); results within fp32 rounding of the direct form (6.0e-7 vs 5.0e-7

@@ -152,11 +152,11 @@ def test_waveglow_256_row_tiles_match_oracle(gpu_engine, wg_weights, wg_cfg):
 
 
 def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_weights, wg_cfg):
-    """The fp32 path evaluates WN layers 1 - 7 in their Winograd F(4,3) form from 384 frames per call (csrc/wn_wino.hip): both
+    """The fp32 path evaluates WN layers 1 - 7 in their Winograd F(4,3) form from 144 frames per call (csrc/wn_wino.hip): both
     forms against the oracle on the same inputs, the switch, the report of which one ran, utterance lengths that leave partial
     frame groups, and the small shapes that keep the direct form."""
     from oracle import waveglow_ref
-    mel, z = _inputs(2, 192, seed=33)                              # 384 frames: the smallest call that takes the Winograd form
+    mel, z = _inputs(2, 192, seed=33)                              # 384 frames (round 3's smallest Winograd call; the form starts at 144 now)
     ref = waveglow_ref.infer(mel, wg_weights, wg_cfg, z=z, sigma=1.0)
     try:
         wino = gpu_engine.waveglow_infer(mel, z=z, sigma=1.0)
@@ -178,8 +178,15 @@ def test_waveglow_winograd_and_direct_forms_against_the_oracle(gpu_engine, wg_we
         e2 = rms(out2 - waveglow_ref.infer(mel2, wg_weights, wg_cfg, z=z2, sigma=1.0))
         print(f'{B2} x {T2} frames: winograd rms_err={e2:.3e}')
         assert e2 <= RMS_TOL
-    # calls below 384 frames keep the direct form (the Winograd form's extra passes cost more than its products save)
-    for B3, T3 in ((1, 16), (2, 128)):
+    # calls below 144 frames keep the direct form (too few blocks for the fused kernel's 64 x 128 tiles: measured break-even
+    # between 100 and 150 frames); the smallest Winograd call, 144 frames on 64-row phase blocks, against the oracle
+    m4, z4 = _inputs(1, 144, seed=37)
+    o4 = gpu_engine.waveglow_infer(m4, z=z4)
+    assert gpu_engine.last_waveglow_form == 'winograd'
+    e4 = rms(o4 - waveglow_ref.infer(m4, wg_weights, wg_cfg, z=z4, sigma=1.0))
+    print(f'1 x 144 frames: winograd rms_err={e4:.3e}')
+    assert e4 <= RMS_TOL
+    for B3, T3 in ((1, 16), (2, 64)):
         m3, z3 = _inputs(B3, T3, seed=35)
         gpu_engine.waveglow_infer(m3, z=z3)
         assert gpu_engine.last_waveglow_form == 'direct'
@@ -195,7 +202,9 @@ def test_winograd_kernel_is_bit_identical_to_its_three_pass_form(gpu_engine):
     sharp test of the fused kernel's LDS-DMA pipeline (a tile read before it landed shows up as a difference, and as a
     difference between two runs): two runs of each shape, shapes with partial frame groups and padded group rows."""
     try:
-        for B, T, seed in ((2, 200, 81), (3, 131, 82), (1, 513, 83)):
+        # (more than 512 frames per call: below that the fused forms run on 64-row phase blocks and the three-pass form on 128-row
+        #  ones, i.e. the first-layer and residual kernels of the forms differ in tile shape)
+        for B, T, seed in ((3, 200, 81), (5, 131, 82), (1, 513, 83)):
             mel, z = _inputs(B, T, seed=seed)
             outs = {}
             for form in ('winograd-3pass', 'winograd-prepass', 'winograd', 'winograd'):

@@ -750,12 +750,16 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     bool row64 = x3 ? pr64 * 1.25 < pr256      // split fp16 has two tile shapes: 64 x 128 (about 25 % more time per row) and 256 x 256
                     : BT <= 512 &&
                       (half ? pr64 * 4 <= pr_big * 3 : pr64 < pr_big);   // fp16: the smaller tile only pays from -25 % rows
-    // fp32: the Winograd form (wn_wino.hip) runs on 128- or 256-row tiles and executes K ~1 120 per output instead of 1 856.
-    // It pays from about 350 frames per call (one sentence, measured: 400 frames 44.4 -> 38.2 ms, 513: 61.2 -> 55.6, 800: 84.7 ->
-    // 67.2; 300 frames break even, 100 frames lose 40 % to its two HBM-bound passes and six-slice launches); a call of that
-    // size whose rows would pad better on 64-row tiles takes the 128-row tiles when that is clearly less work
-    const bool wino_size = precision == 0 && wg.form_mode >= 1 && BT >= 384;
-    if (wino_size && row64 && (double)pr128 * 1120.0 * 1.35 < (double)pr64 * 1856.0) {
+    // fp32: the Winograd form (wn_wino.hip) executes K ~1 090 per output instead of 1 856 in ONE kernel per layer on 64-row tiles.
+    // It pays from about 150 frames per call (one sentence, measured on one box, Winograd / direct: 100 frames 16.9 / 15.0 ms,
+    // 150: 18.3 / 20.9, 200: 19.4 / 26.0, 350: 32.2 / 37.6, 513: 48.5 / 61.2, 800: 64.0 / 84.9; the three-pass form of round 3
+    // only paid from 384 frames: its two HBM-bound passes and six-slice launches cost 40 % at 100 frames)
+#ifndef TTS_WINO_MIN_FRAMES
+#define TTS_WINO_MIN_FRAMES 144
+#endif
+    const bool wino_size = precision == 0 && wg.form_mode >= 1 && BT >= TTS_WINO_MIN_FRAMES;
+    // the three-pass form (measurement form 2) needs 128-row phase blocks; the fused kernels run on 64-row tiles
+    if (wino_size && wg.form_mode == 2 && row64 && (double)pr128 * 1120.0 * 1.35 < (double)pr64 * 1856.0) {
         row64 = false;
         tile128 = pr128 * 1.05 < pr256;
     }
@@ -779,7 +783,7 @@ int waveglow_run(tts_hip_engine* e, const float* d_mel, int B, int T, const floa
     }
     hipStream_t st = e->stream;
     // fp32 path, 128- / 256-row tiles: layers 1 .. 7 of a flow run in their Winograd form (wn_wino.hip)
-    bool wino = wino_size && !row64;                                      // (PR is a multiple of 128)
+    bool wino = wino_size && (!row64 || wg.form_mode != 2);               // (PR is a multiple of 64; form 2: of 128)
     if (wino) {
         // its operands (3.6 GB of weight planes on first use, 0.7 GB of workspace at config 2) are extra: when the device cannot
         // hold them -- and only then: any other error is the call's error -- this handle keeps the direct form from now on

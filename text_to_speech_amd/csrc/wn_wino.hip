@@ -1,4 +1,4 @@
-// wn_wino.hip -- Winograd minimal filtering F(4,3) along the tap axis of the WN dilated convolution (fp32 path, calls of 384
+// wn_wino.hip -- Winograd minimal filtering F(4,3) along the tap axis of the WN dilated convolution (fp32 path, calls of 144
 // frames or more).
 //
 // The in-layer pre-activation of WaveGlow's WN (/root/reference/architectures/waveglow_arch.py:117-127) is a k = 3 dilated
@@ -16,8 +16,8 @@
 // outside an utterance through out-of-range offsets), a product's A fragment is three or four input fragments combined in
 // registers under the other half step's MFMAs, and the epilogue applies the output transform, bias and gate in registers:
 // no U planes, no P planes, no pre-pass or combine launch.  Measured at config 2 on one box: three passes (round 3) 433 ms
-// per step, fused GEMM behind the pre-pass 415, this 409 (direct form 565); the kernel runs the 464 GFLOP a layer executes in
-// 3.72 ms (79 % of the fp32 MFMA peak INCLUDING both transforms and the gate; the per-product GEMM of round 3 alone ran at
+// per step, fused GEMM behind the pre-pass 415, this 401 (direct form 565); the kernel runs the 456 GFLOP a layer executes in
+// 3.62 ms (80 % of the fp32 MFMA peak INCLUDING both transforms and the gate; the per-product GEMM of round 3 alone ran at
 // 85 %, its layer -- 0.19 + 3.55 + 0.27 ms -- at 74 %).  What bounds the tile: six accumulator sets leave room for 64 x 128
 // per four waves at two blocks per CU (8-wave 128 x 128 blocks measured 3 % slower: one barrier domain per CU and 12.5
 // rounds of 256 blocks), i.e. 12 DMA pieces per 16 MFMAs and wave -- twice the direct kernel's bytes per MFMA.

@@ -430,7 +430,7 @@ class HipEngine:
 
     def set_waveglow_form(self, form: str) -> None:
         """How the fp32 vocoder evaluates the dilated convolutions of WN layers 1 - 7: 'winograd' (default: minimal filtering
-        along the tap axis, F(4,3), for calls of 384 frames or more) or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
+        along the tap axis, F(4,3), for calls of 144 frames or more) or 'direct' (always three taps).  Both are fp32; they differ by rounding only."""
         # 'winograd-3pass' / 'winograd-prepass': the two earlier stages of the Winograd form (pre-pass + per-product GEMM + combine
         # pass; fused GEMM behind the pre-pass), kept for measurement and as bit-identical cross-checks of the default kernel
         forms = {'direct': 0, 'winograd': 1, 'winograd-3pass': 2, 'winograd-prepass': 3}
