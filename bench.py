@@ -474,7 +474,7 @@ def launch_ranks(n: int, argv) -> int:
     return worst
 
 
-def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='direct'):
+def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='direct', probe=None):
     """The JSON line without its secondary parts (CPU baseline, config-4 job, extras), from the timed region's numbers."""
     samples = world * B * T * 256 * args.steps
     M = B * T * 32
@@ -517,6 +517,12 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                     'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
                     'algorithmic_bytes': alg_bytes, 'in_layer_form': form,
                     'kernel': kernel, 'launches_timed': launches, 'avg_launch_us': avg_us}
+        if probe:
+            # boxes of the pool differ by up to ~9 % in what their matrix pipe sustains (a bare MFMA loop measured right after the
+            # timed region: 155 TFLOP/s at 2.40 GHz on most boxes, ~142 at ~2.2 GHz on some): the same kernel against THIS box
+            roofline['box_probe_fp32_mfma_tflops'] = probe[0]
+            roofline['box_probe_shader_clock_ghz'] = probe[1]
+            roofline['frac_of_box_probe'] = achieved / probe[0] if probe[0] > 0 else None
     return {
         'metric': 'audio samples/sec (22.05 kHz WaveGlow vocoding, fp32)' if args.precision == 'f32' else
                   f'audio samples/sec (22.05 kHz WaveGlow vocoding, {args.precision})',
@@ -635,6 +641,12 @@ def main():
 
     avg_us, launches = (0.0, 0) if args.no_kernel_timing else eng.kernel_time_us(KERNEL_WN_IN)
     eng.kernel_timing(False)
+    probe = None
+    if rank == 0 and args.precision == 'f32':
+        try:
+            probe = eng.probe_mfma_f32()              # right after the timed region: the box in the state the steps left it in
+        except Exception:
+            probe = None
     form = eng.last_waveglow_form                      # 'winograd' or 'direct': which in-layer GEMM the timed steps ran
     # BASELINE config 4: the scatter / synthesize / gather job, on every rank, at every N.  It must never cost the headline
     # line: an exception is reported inside the line, and a job that does not come back (a rank lost inside a collective
@@ -655,7 +667,7 @@ def main():
     if not args.no_config4:
         import threading
         if rank == 0:
-            headline['result'] = headline_result(args, world, B, T, dt, avg_us, launches, distributed, form)
+            headline['result'] = headline_result(args, world, B, T, dt, avg_us, launches, distributed, form, probe)
             headline['ready'] = True
         watchdog = threading.Timer(CONFIG4_TIMEOUT_S, give_up)
         watchdog.daemon = True
@@ -668,7 +680,7 @@ def main():
     # secondary metrics and the CPU leg only at N = 1 (the other ranks would idle at the final barrier)
     extra = secondary_metrics(eng, dev, rank) if (rank == 0 and world == 1 and not args.no_extra) else None
     if rank == 0:
-        result = headline_result(args, world, B, T, dt, avg_us, launches, distributed, form)
+        result = headline_result(args, world, B, T, dt, avg_us, launches, distributed, form, probe)
         if args.cpu_frames > 0 and world == 1:
             result['cpu_baseline'] = cpu_baseline(w, cfg, args.cpu_frames)
         result['config4_sharded_job'] = config4

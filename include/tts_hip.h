@@ -200,6 +200,9 @@ int tts_hip_mel_stft(tts_hip_engine* e, const float* audio, int B, int N, float*
  * last reset, and how many launches were timed.  kind: 0 = WaveGlow WN in-layer GEMM (layers 1..7 of a flow: K = 2176),
  * 1 = WN residual GEMM, 2 = Tacotron2 decoder step, 3 = first WN layer of a flow (start conv composed: K = 688).  Timing is off unless enabled (events perturb nothing but cost a few us each).        */
 int tts_hip_kernel_timing(tts_hip_engine* e, int enable);
+/* Box probe: TFLOP/s a bare v_mfma_f32_32x32x2_f32 loop sustains on this device right now (every CU, 2 waves per SIMD, ~20 ms)
+ * and the shader clock (GHz) it holds meanwhile -- what the fp32 MFMA roofline of THIS box is; boxes of one pool differ.    */
+int tts_hip_probe_mfma_f32(tts_hip_engine* e, double* tflops, double* shader_clock_ghz);
 int tts_hip_kernel_time_us(tts_hip_engine* e, int kind, double* avg_us, int64_t* launches);
 int tts_hip_synchronize(tts_hip_engine* e);
 

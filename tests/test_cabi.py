@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_null_handle_errors(lib):
-    assert lib.tts_hip_abi_version() == 10
+    assert lib.tts_hip_abi_version() == 11
     assert lib.tts_hip_destroy(None) == -1                       # TTS_HIP_EINVAL, no crash
     assert lib.tts_hip_finalize(None) == -1
     assert lib.tts_hip_has_model(None, b'waveglow') == 0

@@ -15,7 +15,7 @@ LIB_NAME = 'libtts_hip.so'
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MEM_HOST, MEM_DEVICE = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class HipLibraryError(RuntimeError):
@@ -58,6 +58,7 @@ SIGNATURES = {
     'tts_hip_tacotron2_reencode': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'tts_hip_encoded_free': (c_int, [c_void_p, c_void_p]),
     'tts_hip_kernel_timing': (c_int, [c_void_p, c_int]),
+    'tts_hip_probe_mfma_f32': (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     'tts_hip_kernel_time_us': (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     'tts_hip_synchronize': (c_int, [c_void_p]),
 }

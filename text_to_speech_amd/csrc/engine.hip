@@ -136,10 +136,49 @@ int philox_fill(tts_hip_engine* e, float* out, long long n, uint64_t seed, uint6
     return TTS_HIP_OK;
 }
 
+// Box probe (bench.py): what the fp32 matrix pipe of THIS device sustains right now on a bare v_mfma_f32_32x32x2_f32 loop with
+// the register traffic of the WN GEMMs (8 independent accumulators per wave, 2 waves per SIMD, every CU; scripts/micro/
+// mfma_f32_rate.cpp is the stand-alone version: 155.3 TFLOP/s at 2.398 GHz on the round-3 boxes), and the shader clock it
+// holds meanwhile.  Boxes of one pool differ by up to ~9 %: the probe puts a run's numbers in context.
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            unsigned long long* __restrict__ clk, int iters) {
+    probe_f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = in[(threadIdx.x * 16 + i) & 4095];
+        b[i] = in[(threadIdx.x * 16 + 8 + i + blockIdx.x) & 4095];
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(k + i) & 7], b[(k + 3 * i) & 7], acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        clk[0] = t1 - t0;                                // shader clocks
+        clk[1] = r1 - r0;                                // 100 MHz ticks
+    }
+}
+
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int tts_hip_abi_version(void) { return 10; }
+int tts_hip_abi_version(void) { return 11; }
 
 int tts_hip_create(int device, tts_hip_engine** out) {
     if (!out) return TTS_HIP_EINVAL;
@@ -479,6 +518,57 @@ int tts_hip_set_waveglow_form(tts_hip_engine* e, int form) {
 }
 
 int tts_hip_last_waveglow_form(const tts_hip_engine* e) { return e ? e->wg.last_form : -1; }
+
+int tts_hip_probe_mfma_f32(tts_hip_engine* e, double* tflops, double* shader_clock_ghz) {
+    if (!e) return TTS_HIP_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    const int ncu = e->n_cu > 0 ? e->n_cu : 256, blocks = 2 * ncu, iters = 6000;
+    DevBuf in, out, clk;
+    struct Free {
+        DevBuf &a, &b, &c;
+        ~Free() { a.release(); b.release(); c.release(); }
+    } guard{in, out, clk};
+    HIPCHK(e, in.ensure(4096 * 4));
+    HIPCHK(e, out.ensure((size_t)blocks * 256 * 4));
+    HIPCHK(e, clk.ensure(16));
+    std::vector<float> h(4096);
+    uint32_t st = 12345u;
+    for (auto& v : h) {                                  // N(0, 1)-like operands: the clock the part holds depends on the data
+        float u = 0.f;
+        for (int i = 0; i < 12; ++i) {
+            st = st * 1664525u + 1013904223u;
+            u += (float)(st >> 8) * (1.0f / 16777216.0f);
+        }
+        v = u - 6.f;
+    }
+    HIPCHK(e, hipMemcpyAsync(in.p, h.data(), 4096 * 4, hipMemcpyHostToDevice, e->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(e, hipEventCreate(&e0));
+    HIPCHK(e, hipEventCreate(&e1));
+    double best = 0.0, ghz = 0.0;
+    hipError_t err = hipSuccess;
+    for (int rep = 0; rep < 3 && err == hipSuccess; ++rep) {
+        (void)hipEventRecord(e0, e->stream);
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, e->stream, in.f(), out.f(), (unsigned long long*)clk.p, iters);
+        (void)hipEventRecord(e1, e->stream);
+        err = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long c[2] = {0, 1};
+        if (err == hipSuccess) err = hipMemcpy(c, clk.p, 16, hipMemcpyDeviceToHost);
+        const double flop = (double)blocks * 4 * iters * 64.0 * 4096.0;      // 4 waves x iters x 64 MFMAs x (32 x 32 x 2 x 2) FLOP
+        if (err == hipSuccess && ms > 0.f && flop / ms / 1e9 > best) {
+            best = flop / ms / 1e9;
+            ghz = c[1] ? (double)c[0] / ((double)c[1] * 10.0) : 0.0;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(e, err);
+    if (tflops) *tflops = best;
+    if (shader_clock_ghz) *shader_clock_ghz = ghz;
+    return TTS_HIP_OK;
+}
 
 int tts_hip_synchronize(tts_hip_engine* e) {
     if (!e) return TTS_HIP_EINVAL;

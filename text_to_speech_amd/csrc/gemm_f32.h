@@ -914,7 +914,15 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             __builtin_amdgcn_s_barrier();                         // every wave is done reading the last tile
             float* patch = smem + wave * (32 * 36);
             const int prow = lane >> 3, pc4 = (lane & 7) * 4;
-            const bool accum = second ? g.acc1 : g.acc0;
+            bool accum = second ? g.acc1 : g.acc0;
+#if TTS_ABL == 11 || TTS_ABL == 12
+            // ablations 11 / 12 (timing only): the fp16 residual launch without the fp32 master of x -- 11: no read, no fp32 store
+            // (what an fp16-only residual stream would move); 12: the master as an fp16 (hi, lo) pair (4 B in, 4 B out, no shadow)
+            constexpr bool kNoMaster = HALF && TTS_ABL == 11, kPairMaster = HALF && TTS_ABL == 12;
+            if (kNoMaster) accum = false;
+#else
+            constexpr bool kNoMaster = false, kPairMaster = false;
+#endif
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -937,8 +945,18 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], g.act);
                         const long long mrow = mrow0 + prow + 8 * q;
-                        *reinterpret_cast<f32x4*>(outp + mrow * ldo + ncol) = v;
+                        if (!kNoMaster && !kPairMaster) *reinterpret_cast<f32x4*>(outp + mrow * ldo + ncol) = v;
                         if constexpr (HALF) {
+                            if (kPairMaster) {                   // (hi, lo) pair written into the fp32 master's bytes: 4 B per element
+                                typedef _Float16 f16x4p __attribute__((ext_vector_type(4)));
+                                const f16x4p hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                                const f16x4p lv = {(_Float16)(v[0] - (float)hv[0]), (_Float16)(v[1] - (float)hv[1]),
+                                                   (_Float16)(v[2] - (float)hv[2]), (_Float16)(v[3] - (float)hv[3])};
+                                _Float16* mp = reinterpret_cast<_Float16*>(outp + mrow * ldo + ncol);
+                                *reinterpret_cast<f16x4p*>(mp) = hv;
+                                *reinterpret_cast<f16x4p*>(mp + 4) = lv;
+                                continue;
+                            }
                             if (g.out0h && !second) {
                                 typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
                                 const f16x4e hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};

@@ -519,5 +519,11 @@ class HipEngine:
                     'kernel_time_us')
         return avg.value, n.value
 
+    def probe_mfma_f32(self):
+        """(TFLOP/s, shader clock in GHz) of a bare fp32 MFMA loop on this device right now (tts_hip_probe_mfma_f32, ~60 ms)."""
+        tf, ghz = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.tts_hip_probe_mfma_f32(self._h, ctypes.byref(tf), ctypes.byref(ghz)), 'probe_mfma_f32')
+        return tf.value, ghz.value
+
     def synchronize(self) -> None:
         self._check(self._lib.tts_hip_synchronize(self._h), 'synchronize')
