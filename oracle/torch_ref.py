@@ -18,7 +18,9 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def torch_waveglow(mel, w, cfg, z, sigma=1.0):
+def torch_waveglow(mel, w, cfg, z, sigma=1.0, collect=None):
+    """`collect` (a dict): the gated activations of every WN layer, keyed (flow, layer), as [B, L, C] arrays -- the
+    intermediates the layer-level parity tests compare (the numpy oracle's `wn_block(collect=...)`)."""
     g = cfg.n_group
     spect = F.conv_transpose1d(_t(mel).transpose(1, 2), _t(w['waveglow/upsample/kernel']).permute(2, 1, 0),
                                _t(w['waveglow/upsample/bias']), stride=cfg.upsample_stride)
@@ -44,6 +46,8 @@ def torch_waveglow(mel, w, cfg, z, sigma=1.0):
                             _t(w[f'{p}/cond_layer-{i}/bias']))
             s = acts_in + cond
             acts = torch.tanh(s[:, :C]) * torch.sigmoid(s[:, C:])
+            if collect is not None:
+                collect[(k, i)] = acts.permute(0, 2, 1).contiguous().numpy()
             rs = F.conv1d(acts, _t(w[f'{p}/res_skip_conv-{i}/kernel']).permute(2, 1, 0),
                           _t(w[f'{p}/res_skip_conv-{i}/bias']))
             if i < cfg.n_layers - 1:

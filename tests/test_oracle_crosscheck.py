@@ -26,6 +26,32 @@ def test_waveglow_oracle_vs_torch(B, T):
     assert np.abs(ref - out).max() < 1e-4
 
 
+def test_wn_layer_activations_oracle_vs_torch():
+    """The layer-level GPU parity test (tests/test_waveglow_gpu.py) compares one WN layer's gated activations with the numpy
+    oracle's `wn_block(collect=...)` intermediates: those intermediates against the independent torch restatement, for every
+    layer of the first flow that runs (flow 11), on a model with full depth / dilations and 64 channels."""
+    from oracle import waveglow_ref
+    from text_to_speech_amd import weights
+    from text_to_speech_amd.config import WaveGlowConfig
+    cfg = WaveGlowConfig(n_channels=64, n_layers=8)
+    w = weights.synth_waveglow(cfg, seed=5)
+    rng = np.random.default_rng(3)
+    mel = rng.uniform(-11.5, 1.2, (2, 9, 80)).astype(np.float32)
+    z = rng.standard_normal((2, 9 * 32, 8)).astype(np.float32)
+    got = {}
+    torch_waveglow(mel, w, cfg, z, collect=got)
+    wf = {k: v for k, v in w.items() if k.startswith('waveglow/')}
+    spect = waveglow_ref.regroup(waveglow_ref.upsample(mel, wf['waveglow/upsample/kernel'], wf['waveglow/upsample/bias'],
+                                                       cfg.upsample_stride), cfg.n_group)
+    acts = []
+    waveglow_ref.wn_block(z[:, :, :cfg.n_remaining_channels // 2], spect, wf, 'waveglow/block-11', cfg.n_layers, cfg.n_channels,
+                          collect=acts, stop_after=6)
+    assert len(acts) == 7                                   # `stop_after=6`: layers 0 .. 6
+    for i, a in enumerate(acts):
+        assert a.shape == got[(11, i)].shape == (2, 9 * 32, 64)
+        assert np.abs(a - got[(11, i)]).max() < 1e-5, i
+
+
 @pytest.mark.parametrize('spk_dim', [0, 256])
 def test_tacotron2_oracle_vs_torch(spk_dim):
     from oracle import tacotron2_ref
