@@ -517,6 +517,11 @@ def headline_result(args, world, B, T, dt, avg_us, launches, distributed, form='
                     'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)',
                     'algorithmic_bytes': alg_bytes, 'in_layer_form': form,
                     'kernel': kernel, 'launches_timed': launches, 'avg_launch_us': avg_us}
+        # north_star also asks for the fraction of the HBM roofline on the WN sweep: algorithmic bytes (and, when the PMC passes of
+        # this workload exist, the measured L2-miss traffic) of one launch over its time, against 8 TB/s.  MFMA-bound by construction.
+        roofline['hbm_frac_algorithmic'] = alg_bytes / (avg_us * 1e-6) / (HBM_PEAK_TBS * 1e12)
+        if roofline['traffic']:
+            roofline['hbm_frac_traffic'] = roofline['traffic'] / (avg_us * 1e-6) / (HBM_PEAK_TBS * 1e12)
         if probe:
             # boxes of the pool differ by up to ~9 % in what their matrix pipe sustains (a bare MFMA loop measured right after the
             # timed region: 155 TFLOP/s at 2.40 GHz on most boxes, ~142 at ~2.2 GHz on some): the same kernel against THIS box
