@@ -373,6 +373,35 @@ __device__ __forceinline__ void poll_pairs(const WavePoll& P, const unsigned (&e
     for (int i = 0; i < N; ++i) out[i] = f32x2{bitsf(v[i][0]), bitsf(v[i][2])};
 }
 
+// Quiet windows (TTS_FUSED_QUIET, experiment of round 4): a hop's price sits in the consumer's memory queue and on a fabric that
+// the weight stream keeps busy.  A role wave raises an LDS counter from the moment its producer has published until its own poll
+// has succeeded; the LSTM waves do not request new weight slices while the counter is up (the 256 blocks run in lock step, so the
+// whole chip's stream pauses around every hop).  Bounded wait: the stream resumes on its own after ~0.1 ms.
+#ifndef TTS_FUSED_QUIET
+#define TTS_FUSED_QUIET 3          // bit 0: the p1 hop of kernel X, bit 2: its p2 hop, bit 1: the hops of kernel Y
+#endif
+#ifndef TTS_FUSED_QUIET_LEAD
+#define TTS_FUSED_QUIET_LEAD 30    // > 0: the window opens this many 10-ns ticks before the first look instead of at the publish
+#endif
+template <int KERNEL>
+__device__ __forceinline__ void quiet_begin(lds_int* ctl, int lane) {
+    if constexpr ((TTS_FUSED_QUIET >> KERNEL) & 1)
+        if (lane == 0) __hip_atomic_fetch_add(ctl + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int KERNEL>
+__device__ __forceinline__ void quiet_end(lds_int* ctl, int lane) {
+    if constexpr ((TTS_FUSED_QUIET >> KERNEL) & 1)
+        if (lane == 0) __hip_atomic_fetch_add(ctl + 7, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the delay a role wave sleeps through BEFORE it opens its quiet window
+__device__ __forceinline__ int quiet_pre(int delay) { return TTS_FUSED_QUIET_LEAD > 0 ? max(0, delay - TTS_FUSED_QUIET_LEAD) : 0; }
+__device__ __forceinline__ void stream_gate(const lds_int* ctl) {
+#if TTS_FUSED_QUIET
+    int spins = 0;
+    while (lds_peek(ctl + 7) > 0 && ++spins < 2048) __builtin_amdgcn_s_sleep(2);
+#endif
+}
+
 // ================================================================================================== kernel X
 // tail != 0: only the frame / stop-token part (end of a chunk).
 template <int NBT, int ENC, bool HW>
@@ -516,6 +545,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
             }
             fma_slice<NBT>(acc, w.g[0], w.g[1], w.g[2], w.g[3], xs + excol(e), KX, lane);
             asm volatile("" ::: "memory");            // the refill is requested here, not hoisted to the top
+            stream_gate(ctl);
             if (e + PF < NE) load_slice<HW, !HW>(w, a.Wa, row0, KA, ekoff(e + PF), lane);
             else if (e + PF == NE) load_slice<HW, !HW>(wl, a.Wa, row0, KA, 0, lane);       // the p2 slice last: it waits for the chain
             asm volatile("" ::: "memory");
@@ -603,10 +633,14 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
             ent[2 * b] = X.p1 + bb * PRE + lane * 4;
             ent[2 * b + 1] = ent[2 * b] + 2;
         }
+        wait_stamp(P, ctl + 2, quiet_pre(a.delay[0]));
+        wait_stamp(P, ctl + 3, quiet_pre(a.delay[0]));
+        quiet_begin<0>(ctl, lane);
         wait_stamp(P, ctl + 2, a.delay[0]);
         wait_stamp(P, ctl + 3, a.delay[0]);
         f32x2 pv[2 * NBT];
         poll_pairs<2 * NBT>(P, ent, tag, pv);
+        quiet_end<0>(ctl, lane);
         float sm[NBT];
 #pragma unroll
         for (int b = 0; b < NBT; ++b) {
@@ -627,9 +661,12 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
             pair[i] = r * (NQ * 64) + i * 64 + lane;
             ent[i] = X.p2 + 2u * (unsigned)(pair[i] < B * PRE / 2 ? pair[i] : 0);
         }
+        wait_stamp(P, ctl + 4, quiet_pre(a.delay[1]));
+        quiet_begin<2>(ctl, lane);
         wait_stamp(P, ctl + 4, a.delay[1]);
         f32x2 pv[NQ];
         poll_pairs<NQ>(P, ent, tag, pv);
+        quiet_end<2>(ctl, lane);
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
             if (pair[i] < B * PRE / 2) *reinterpret_cast<f32x2*>(p2s + 2 * pair[i]) = pv[i];
@@ -761,6 +798,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             }
             fma_slice<NBT>(acc, w.g[0], w.g[1], w.g[2], w.g[3], xs + ecol(e), KX, lane);
             asm volatile("" ::: "memory");            // the refill is requested here, not hoisted to the top
+            stream_gate(ctl);
             if (e + PF < NE) load_slice<HW, true>(w, a.Wd, row0, KX, ecol(e + PF), lane);
             else if (e + PF - NE < NC) load_slice<HW, true>(wlate[e + PF - NE], a.Wd, row0, KX, RNN + (e + PF - NE) * 256, lane);   // ctx slices last
             asm volatile("" ::: "memory");
@@ -908,10 +946,15 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
                 loc[0] = fmaf(sc, w1[0], loc[0]);
                 loc[1] = fmaf(sc, w1[1], loc[1]);
             }
-            if (p == 0) wait_stamp(P, ctl + 2, a.delay[2]);
+            if (p == 0) {
+                wait_stamp(P, ctl + 2, quiet_pre(a.delay[2]));
+                quiet_begin<1>(ctl, lane);
+                wait_stamp(P, ctl + 2, a.delay[2]);
+            }
             unsigned ent[1] = {X.q + (unsigned)b * ATT + (unsigned)lane * 2};
             f32x2 qv[1];
             poll_pairs<1>(P, ent, tag, qv);
+            if (p == 0) quiet_end<1>(ctl, lane);
             if (r == 0 && p == 0) FTR(1, 4);
             float e = vv[0] * tanh_fast(qv[0][0] + loc[0]);
             e = fmaf(vv[1], tanh_fast(qv[0][1] + loc[1]), e);
@@ -931,9 +974,12 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             const int tau = 128 * k + 2 * lane;
             ent[k] = rowe + (unsigned)(tau < X.TinP ? tau : 0);
         }
+        wait_stamp(P, ctl + 3, quiet_pre(a.delay[3]));
+        quiet_begin<1>(ctl, lane);
         wait_stamp(P, ctl + 3, a.delay[3]);
         f32x2 ev[KT];
         poll_pairs<KT>(P, ent, tag, ev);              // (also drains this wave's LDS-DMA of the memory slice: vmcnt is in order)
+        quiet_end<1>(ctl, lane);
         if (r == 0) FTR(1, 6);
         // attention window (tacotron2_arch.py:630-638); inclusive upper bound
         int lo = 0, hi = Tin;
@@ -1028,9 +1074,12 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             pair[i] = r * (NQ * 64) + i * 64 + lane;
             ent[i] = X.ctx + 2u * (unsigned)(pair[i] < B * ENC / 2 ? pair[i] : 0);
         }
+        wait_stamp(P, ctl + 4, quiet_pre(a.delay[4]));
+        quiet_begin<1>(ctl, lane);
         wait_stamp(P, ctl + 4, a.delay[4]);
         f32x2 cv[NQ];
         poll_pairs<NQ>(P, ent, tag, cv);
+        quiet_end<1>(ctl, lane);
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
             if (pair[i] < B * ENC / 2) {
@@ -1150,7 +1199,7 @@ int fused_enqueue_chunk(tts_hip_engine* e, hipStream_t st, const FusedCall& c) {
     a.trace = c.trace;
     // first look at a hop this long after the block's own producer published (10-ns ticks): the latency of a tagged publish
     // under the weight stream; found with scripts/fused_sweep.py.  A wrong value costs time, never correctness.
-    static const int kDelay[5] = {90, 90, 115, 115, 100};
+    static const int kDelay[5] = {40, 90, 115, 115, 100};     // (round 4: the p1 hop is looked at earlier now that the stream pauses for it)
     for (int i = 0; i < 5; ++i) a.delay[i] = kDelay[i];
 #ifdef TTS_DEBUG_HOOKS
     if (const char* dl = getenv("TTS_FUSED_DELAYS")) {            // "a,b,c,d,e"
