@@ -373,6 +373,30 @@ __device__ __forceinline__ void poll_pairs(const WavePoll& P, const unsigned (&e
     for (int i = 0; i < N; ++i) out[i] = f32x2{bitsf(v[i][0]), bitsf(v[i][2])};
 }
 
+// Loop state and abort flag of a kernel's entry, requested TOGETHER and only then looked at.  (Read as `*a.st` followed by the
+// flag behind the first early return, hipcc fetched the fields in two rounds and the flag in a third: three dependent memory
+// latencies between dispatch and the first useful instruction of every wave.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct EntryLoads { i32x4 lo, hi; int flag; };
+struct EntryState { FusedState s; int flag; };
+// issue: right behind the first staging loads, in front of every other request of the entry (results return in issue order)
+__device__ __forceinline__ EntryLoads request_entry(const FusedState* st, const int* flags) {
+    EntryLoads l;
+    l.lo = *reinterpret_cast<const i32x4*>(st);
+    l.hi = *(reinterpret_cast<const i32x4*>(st) + 1);
+    l.flag = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return l;
+}
+// look: all three at once
+__device__ __forceinline__ EntryState look_entry(EntryLoads l) {
+    asm volatile("" : "+v"(l.lo), "+v"(l.hi), "+v"(l.flag));
+    EntryState e;
+    e.s.t0 = l.lo[0]; e.s.n_fin = l.lo[1]; e.s.steps_run = l.lo[2]; e.s.exec_t = l.lo[3];
+    e.s.B = l.hi[0]; e.s.max_len = l.hi[1]; e.s.early_stop = l.hi[2]; e.s.pad = l.hi[3];
+    e.flag = l.flag;
+    return e;
+}
+
 // Quiet windows (TTS_FUSED_QUIET, experiment of round 4): a hop's price sits in the consumer's memory queue and on a fabric that
 // the weight stream keeps busy.  A role wave raises an LDS counter from the moment its producer has published until its own poll
 // has succeeded; the LSTM waves do not request new weight slices while the counter is up (the 256 blocks run in lock step, so the
@@ -416,7 +440,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
     float* p2s = xs + NBT * KX;                       // [NBT][256]
     lds_int* ctl = (lds_int*)(p2s + NBT * PRE);       // [0] abort, [1] finished count, [2..4] publish times: p1 (two waves), p2
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
     const int B = a.B;
     const int par = j & 1;                            // = t & 1 (chunks are even): h(t - 1) lives in buffer t & 1, h(t) goes to the other one
     // Everything requested before the loop state is looked at: the state is the third load of a dependent chain (kernel
@@ -440,6 +464,7 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
             sv[i] = v;
         }
     }
+    const EntryLoads el = request_entry(a.st, a.flags);
     constexpr int NC_ = ENC / 256;
     auto ekoff = [](int e) { return e < NC_ ? PRE + e * 256 : PRE + ENC + (e - NC_) * 256; };      // column inside the weight row
     f32x4 hv[NS2];                                    // LSTM waves: this thread's share of h_att(t-1)
@@ -479,10 +504,11 @@ __global__ __launch_bounds__(NTHR) void fused_x_kernel(const FusedArgs a, const 
         for (int e = 0; e < PRE_SL; ++e) load_slice<HW, !HW>(win[e], a.Wa, 4ll * (blk * 4 + wave), KA, ekoff(e), lane);
     }
     asm volatile("" ::: "memory");
-    const FusedState s = *a.st;
+    const EntryState es = look_entry(el);
+    const FusedState& s = es.s;
     const int t = s.t0 + j;
     if (s.steps_run != t) return;                     // the loop ended before this step
-    if (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;       // an earlier kernel gave up
+    if (es.flag != 0) return;                         // an earlier kernel gave up
     const bool frame_on = t >= 1 && (j >= 1 || tail != 0);       // frame / stop token of step t - 1 (j == 0: the previous chunk's tail did it)
     const bool step_on = tail == 0 && t < s.max_len;
     if (!frame_on && !step_on) return;
@@ -699,7 +725,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     float* msl = wsm + 4 * TP;                        // [4 role waves][TP][8] encoder outputs: 8 columns of one row
     lds_int* ctl = (lds_int*)(msl + 4 * TP * 8);      // [0] abort, [2..4] publish times: q, energies, context
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
     const int B = a.B, Tin = a.Tin;
     const int par = j & 1;                            // = t & 1: h_att(t) is in buffer par ^ 1, h_dec(t - 1) in buffer par
     // everything requested before the loop state is looked at (see kernel X)
@@ -719,15 +745,14 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             sv[i] = v;
         }
     }
+    const EntryLoads el = request_entry(a.st, a.flags);
     auto ecol = [](int e) { return e < 4 ? e * 256 : RNN + ENC + (e - 4) * 256; };
     f32x4 hv[NS2];                                    // LSTM waves: this thread's share of h_dec(t-1)
     WSlice<HW> win[PF];
-    f32x4 RQ[4];                                      // query wave (role wave 3): its row of the query matrix (see kernel X)
-    {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 RQ[4];                                      // query wave (role wave 3) only: its row of the query matrix (see kernel X)
+    if (wave == 7) {                                  // (no zeros for the other waves: the merge cost the query wave a full wait)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            RQ[i] = wave == 7 ? *reinterpret_cast<const f32x4*>(a.Wq + (size_t)(blk & (ATT - 1)) * RNN + i * 256 + lane * 4) : zero;
+        for (int i = 0; i < 4; ++i) RQ[i] = *reinterpret_cast<const f32x4*>(a.Wq + (size_t)(blk & (ATT - 1)) * RNN + i * 256 + lane * 4);
     }
     if (wave < 4) {
         const float* hd = a.hdec + (size_t)par * B * RNN;
@@ -742,11 +767,62 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
 #pragma unroll
         for (int e = 0; e < PRE_SL; ++e) load_slice<HW, true>(win[e], a.Wd, 4ll * (blk * 4 + wave), KX, ecol(e), lane);
     }
+    // --- operands of the role waves' roles: none of them depends on the loop state, so they are requested in front of it too
+    // (round 4: behind it they cost barrier #1 one more memory latency; the token mask, looked at on the spot, two more)
+    const int r = wave - 4;
+    const bool role = wave >= 4;
+    const int g_id = r * NBLK + blk;                  // 0 .. 1023 (role waves)
+    // query: r == 3 of block blk computes attention dim blk & 127 of rows [0, HB) (blk < 128) or [HB, NBT) (blk >= 128)
+    const bool is_q = r == 3;
+    const int qdim = blk & (ATT - 1), qrow = blk < ATT ? 0 : HB;
+    f32x2 vv = {0.f, 0.f};
+    if (role) vv = *reinterpret_cast<const f32x2*>(a.vw + lane * 2);
+    f32x2 pmv[NPOS];
+    float cp[NPOS], cc[NPOS];                         // alignment windows: lane i < 31 holds position tau + i - 15
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p) {
+        const int idx = g_id + 1024 * p;
+        const f32x2 zero2 = {0.f, 0.f};
+        pmv[p] = zero2;
+        cp[p] = cc[p] = 0.f;
+        if (role && idx < B * Tin) {
+            const int b = idx / Tin, tau = idx - b * Tin;
+            pmv[p] = *reinterpret_cast<const f32x2*>(a.pm + (size_t)idx * ATT + lane * 2);
+            const int tw = tau + lane - LOCK / 2;
+            if (lane < LOCK && tw >= 0 && tw < Tin) {
+                cp[p] = a.wprev[(size_t)b * Tin + tw];
+                cc[p] = a.wcum[(size_t)b * Tin + tw];
+            }
+        }
+    }
+    const bool has_ctx = role && g_id < B * CU_PER_ROW;
+    constexpr int R_LAST_CTX = (NBT * CU_PER_ROW - 1) / NBLK;      // (upper bound of) the last role wave that owns a context unit
+    const int cb = has_ctx ? g_id / CU_PER_ROW : 0, c8 = has_ctx ? g_id % CU_PER_ROW : 0;
+    unsigned mraw[2 * KT];                            // token mask bytes of positions 128 k + 2 lane (+ 1): requested here, looked at behind barrier #1
+    float wc_old[2 * KT];
+    int elen = 0, matt_old = 0;
+#pragma unroll
+    for (int i = 0; i < 2 * KT; ++i) { wc_old[i] = 0.f; mraw[i] = 0; }
+    if (has_ctx) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tau = 128 * k + 2 * lane + h;
+                if (tau < Tin) {
+                    mraw[2 * k + h] = a.mask[(size_t)cb * Tin + tau];
+                    if (c8 == 0) wc_old[2 * k + h] = a.wcum[(size_t)cb * Tin + tau];
+                }
+            }
+        elen = a.enc_len[cb];
+        matt_old = a.mainatt[par * B + cb];
+    }
     asm volatile("" ::: "memory");
-    const FusedState s = *a.st;
+    const EntryState es = look_entry(el);
+    const FusedState& s = es.s;
     const int t = s.t0 + j;
     if (s.exec_t != t + 1) return;                    // X(t) decided that the loop has ended (or never ran)
-    if (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (es.flag != 0) return;
     const int max_len = s.max_len;
     const unsigned tag = (unsigned)t + 1;
     const FX X = fx_layout(B, Tin, ENC);
@@ -819,62 +895,21 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
         return;
     }
     // ---------------------------------------------------------------------------------------------- role waves
-    const int r = wave - 4;
     __builtin_amdgcn_s_setprio(3);
-    const int g_id = r * NBLK + blk;                  // 0 .. 1023
     WavePoll P;
     P.rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, 0x80000000u, 0x00020000);
     P.flags = a.flags;
     P.abort_s = ctl;
-    // --- operands of this wave's roles (requested behind the staging loads, before they are waited for)
-    // query: r == 3 of block blk computes attention dim blk & 127 of rows [0, HB) (blk < 128) or [HB, NBT) (blk >= 128)
-    const bool is_q = r == 3;
-    const int qdim = blk & (ATT - 1), qrow = blk < ATT ? 0 : HB;
-    const f32x2 vv = *reinterpret_cast<const f32x2*>(a.vw + lane * 2);
-    f32x2 pmv[NPOS];
-    float cp[NPOS], cc[NPOS];                         // alignment windows: lane i < 31 holds position tau + i - 15
-#pragma unroll
-    for (int p = 0; p < NPOS; ++p) {
-        const int idx = g_id + 1024 * p;
-        const f32x2 zero2 = {0.f, 0.f};
-        pmv[p] = zero2;
-        cp[p] = cc[p] = 0.f;
-        if (idx < B * Tin) {
-            const int b = idx / Tin, tau = idx - b * Tin;
-            pmv[p] = *reinterpret_cast<const f32x2*>(a.pm + (size_t)idx * ATT + lane * 2);
-            const int tw = tau + lane - LOCK / 2;
-            if (lane < LOCK && tw >= 0 && tw < Tin) {
-                cp[p] = a.wprev[(size_t)b * Tin + tw];
-                cc[p] = a.wcum[(size_t)b * Tin + tw];
-            }
-        }
-    }
-    const bool has_ctx = g_id < B * CU_PER_ROW;
-    constexpr int R_LAST_CTX = (NBT * CU_PER_ROW - 1) / NBLK;      // (upper bound of) the last role wave that owns a context unit
-    const int cb = has_ctx ? g_id / CU_PER_ROW : 0, c8 = has_ctx ? g_id % CU_PER_ROW : 0;
-    unsigned on_bits = 0;                             // token mask of positions 128 k + 2 lane (+ 1): bits 2 k, 2 k + 1
-    float wc_old[2 * KT];
-    int elen = 0, matt_old = 0;
-#pragma unroll
-    for (int i = 0; i < 2 * KT; ++i) wc_old[i] = 0.f;
-    if (has_ctx) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int tau = 128 * k + 2 * lane + h;
-                if (tau < Tin) {
-                    if (a.mask[(size_t)cb * Tin + tau]) on_bits |= 1u << (2 * k + h);
-                    if (c8 == 0) wc_old[2 * k + h] = a.wcum[(size_t)cb * Tin + tau];
-                }
-            }
-        elen = a.enc_len[cb];
-        matt_old = a.mainatt[par * B + cb];
-    }
     store_staged();
     if (r == 0) FTR(1, 1);
     __syncthreads();                                  // #1
     if (r == 0) FTR(1, 2);
+    unsigned on_bits = 0;                             // bits 2 k, 2 k + 1
+#pragma unroll
+    for (int i = 0; i < 2 * KT; ++i) {
+        asm volatile("" : "+v"(mraw[i]));
+        if (mraw[i]) on_bits |= 1u << i;
+    }
     {   // the location map (31 KiB, only the energies need it): fetched by the role waves now, while the query is computed
         // and published, instead of sitting in front of barrier #1; the four waves meet on an LDS counter
         const int rt = tid - 256;
