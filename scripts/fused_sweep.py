@@ -24,7 +24,7 @@ def step_us(delays):
     ts = {}
     for n in (300, 600):
         best = 1e9
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             eng.tacotron2_infer(tok_d, max_len=n, early_stopping=False, want_attention=False, precision=prec)
             best = min(best, time.perf_counter() - t0)
@@ -32,7 +32,7 @@ def step_us(delays):
     return 1e6 * (ts[600] - ts[300]) / 300
 
 
-cur = [90, 90, 80, 80, 100]
+cur = [int(v) for v in os.environ.get('SWEEP_START', '40,90,115,115,100').split(',')]
 eng.tacotron2_infer(tok_d, max_len=64, early_stopping=False, want_attention=False, precision=prec)
 best = step_us(cur)
 print(f'B={B} {prec} start {cur}: {best:.2f} us/step', flush=True)
@@ -44,6 +44,7 @@ for rnd in range(2):
             trial = list(cur)
             trial[h] = cand
             v = step_us(trial)
+            print(f'   hop {h} = {cand}: {v:.2f}', flush=True)
             if v < best - 0.05:
                 best, cur = v, trial
         print(f'round {rnd} hop {h}: {cur} -> {best:.2f} us/step', flush=True)

@@ -1233,9 +1233,12 @@ int fused_enqueue_chunk(tts_hip_engine* e, hipStream_t st, const FusedCall& c) {
     a.dec_out = c.dec_out; a.stop_out = c.stop_out; a.attn_hist = c.attn_hist; a.lengths = c.lengths; a.finished = c.finished;
     a.trace = c.trace;
     // first look at a hop this long after the block's own producer published (10-ns ticks): the latency of a tagged publish
-    // under the weight stream; found with scripts/fused_sweep.py.  A wrong value costs time, never correctness.
-    static const int kDelay[5] = {40, 90, 115, 115, 100};     // (round 4: the p1 hop is looked at earlier now that the stream pauses for it)
-    for (int i = 0; i < 5; ++i) a.delay[i] = kDelay[i];
+    // next to the (pausing) weight stream.  Found per kernel shape with scripts/fused_sweep.py on the debug build (round 4: the
+    // sweep now really changes the delays of the graph it times); a wrong value costs time, never correctness.
+    static const int kDelay[2][2][5] = {
+        {{70, 80, 120, 60, 100}, {20, 40, 120, 20, 60}},       // 4-row kernels: fp32 weights, fp16 weights
+        {{30, 90, 150, 60, 60}, {40, 40, 120, 20, 70}}};       // 8-row kernels
+    for (int i = 0; i < 5; ++i) a.delay[i] = kDelay[c.B > 4 ? 1 : 0][c.half_w ? 1 : 0][i];
 #ifdef TTS_DEBUG_HOOKS
     if (const char* dl = getenv("TTS_FUSED_DELAYS")) {            // "a,b,c,d,e"
         int v[5];

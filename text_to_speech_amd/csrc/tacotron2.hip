@@ -1606,10 +1606,13 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         const bool fgraph = getenv("TTS_HIP_NO_GRAPH") == nullptr;
         const char* trace_file = getenv("TTS_FUSED_TRACE_FILE");       // phase timestamps of the first 128 steps (scripts/fused_trace.py)
         const size_t trace_n = (size_t)128 * 2 * 4 * 16;
-        if (trace_file) {
-            HIPCHK(e, hipMalloc((void**)&fc.trace, trace_n * sizeof(long long)));
-            HIPCHK(e, hipMemsetAsync(fc.trace, 0, trace_n * sizeof(long long), st));
-            hipGraph_t graph = nullptr;                                 // a graph of its own: the trace pointer is baked in
+        const bool own_graph = trace_file || getenv("TTS_FUSED_DELAYS");   // (the delays are kernel arguments of the cached graph)
+        if (own_graph) {
+            if (trace_file) {
+                HIPCHK(e, hipMalloc((void**)&fc.trace, trace_n * sizeof(long long)));
+                HIPCHK(e, hipMemsetAsync(fc.trace, 0, trace_n * sizeof(long long), st));
+            }
+            hipGraph_t graph = nullptr;                                 // a graph of its own: the trace pointer / delays are baked in
             HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int crc = fused_enqueue_chunk(e, st, fc);
             HIPCHK(e, hipStreamEndCapture(st, &graph));
@@ -1620,8 +1623,9 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
 #else
         constexpr bool fgraph = true;
         constexpr const char* trace_file = nullptr;
+        constexpr bool own_graph = false;
 #endif
-        if (fgraph && !trace_file) {
+        if (fgraph && !own_graph) {
             const DecGraphKey key{tc.ws.p, en->buf.p, B, Tin, (int)max_len_b, with_masks ? 1 : 0, win_len, win_offset,
                                   half_w ? 1 : 0, layout_id | 4};
             if ((rc = cached_graph(key, [&]() { return fused_enqueue_chunk(e, st, fc); }, &gexec))) return rc;
@@ -1681,6 +1685,7 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
             HIPCHK(e, hipGetLastError());
         }
 #ifdef TTS_DEBUG_HOOKS
+        if (own_graph && !fc.trace) (void)hipGraphExecDestroy(gexec);
         if (fc.trace) {
             std::vector<long long> ht(trace_n);
             (void)hipMemcpy(ht.data(), fc.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost);
