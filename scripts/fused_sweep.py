@@ -14,8 +14,10 @@ eng = HipEngine(0)
 eng.load_state(weights.synth_tacotron2(Tacotron2Config(), seed=1234))
 eng.finalize()
 eng.set_decoder_mode('fused')
-tok = np.zeros((B, 128), np.int32)
-tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
+Tin = int(os.environ.get('FUSED_TIME_TIN', '128'))
+n_tok = max(2, Tin * 100 // 128)
+tok = np.zeros((B, Tin), np.int32)
+tok[:, :n_tok] = np.random.default_rng(5).integers(1, 148, (B, n_tok))
 tok_d = torch.from_numpy(tok).cuda()
 
 
@@ -38,7 +40,7 @@ best = step_us(cur)
 print(f'B={B} {prec} start {cur}: {best:.2f} us/step', flush=True)
 for rnd in range(2):
     for h in range(5):
-        for cand in (0, 20, 40, 60, 80, 100, 120, 150):
+        for cand in (0, 30, 60, 90, 120, 150, 200, 250, 300):
             if cand == cur[h]:
                 continue
             trial = list(cur)

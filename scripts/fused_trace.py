@@ -15,8 +15,10 @@ eng = HipEngine(0)
 eng.load_state(weights.synth_tacotron2(Tacotron2Config(), seed=1234))
 eng.finalize()
 eng.set_decoder_mode('fused')
-tok = np.zeros((B, 128), np.int32)
-tok[:, :100] = np.random.default_rng(5).integers(1, 148, (B, 100))
+Tin = int(os.environ.get('FUSED_TIME_TIN', '128'))
+n_tok = max(2, Tin * 100 // 128)
+tok = np.zeros((B, Tin), np.int32)
+tok[:, :n_tok] = np.random.default_rng(5).integers(1, 148, (B, n_tok))
 tok_d = torch.from_numpy(tok).cuda()
 for _ in range(2):
     eng.tacotron2_infer(tok_d, max_len=160, early_stopping=False, want_attention=False, precision=prec)

@@ -1622,7 +1622,6 @@ static int tacotron2_decode_impl(tts_hip_engine* e, const tts_hip_encoded* en, i
         }
 #else
         constexpr bool fgraph = true;
-        constexpr const char* trace_file = nullptr;
         constexpr bool own_graph = false;
 #endif
         if (fgraph && !own_graph) {
