@@ -40,7 +40,7 @@ best = step_us(cur)
 print(f'B={B} {prec} start {cur}: {best:.2f} us/step', flush=True)
 for rnd in range(2):
     for h in range(5):
-        for cand in (0, 30, 60, 90, 120, 150, 200, 250, 300):
+        for cand in (0, 20, 40, 60, 80, 100, 120, 150, 200):
             if cand == cur[h]:
                 continue
             trial = list(cur)

@@ -339,8 +339,12 @@ __device__ __forceinline__ int stage_index(int idx, int blk, int total) {
 // (100 MHz) time of its publish, sleeps until that time + the hop's latency, and only then loads its pairs -- usually once.
 // Tags decide, time only chooses when to look.  Hops: 0 p1, 1 p2, 2 q, 3 energies, 4 context.
 constexpr long long LDS_SPIN_LIMIT = 1 << 22;
-__device__ __forceinline__ void stamp(lds_int* ts) {
-    lds_poke(ts, (int)((unsigned)wall_clock64() | 1u));
+__device__ __forceinline__ void stamp(lds_int* ts, int later = 0) {
+    lds_poke(ts, (int)(((unsigned)wall_clock64() + (unsigned)later) | 1u));
+}
+// One stamp per hop and block, left by whichever of its `n` producing waves publishes LAST (they count themselves on an LDS word).
+__device__ __forceinline__ void stamp_last(lds_int* count, int n, lds_int* ts) {
+    if (__hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == n - 1) stamp(ts);
 }
 __device__ __forceinline__ void wait_stamp(const WavePoll& P, const lds_int* ts, int delay) {
     long long spins = 0;
@@ -723,7 +727,8 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     float* wl = xs + NBT * KX;                        // [62][128]
     float* wsm = wl + 2 * LOCK * ATT;                 // [4 role waves][TP] softmax weights
     float* msl = wsm + 4 * TP;                        // [4 role waves][TP][8] encoder outputs: 8 columns of one row
-    lds_int* ctl = (lds_int*)(msl + 4 * TP * 8);      // [0] abort, [2..4] publish times: q, energies, context
+    lds_int* ctl = (lds_int*)(msl + 4 * TP * 8);      // [0] abort, [2..4] publish times: q, energies, context; [5..7] counters of
+                                                      // the staging / quiet windows, [8] [9] energies / context publishers done
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
     const int B = a.B, Tin = a.Tin;
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
         }
     }
     const bool has_ctx = role && g_id < B * CU_PER_ROW;
-    constexpr int R_LAST_CTX = (NBT * CU_PER_ROW - 1) / NBLK;      // (upper bound of) the last role wave that owns a context unit
+    const int n_c = min(4, max(0, (B * CU_PER_ROW - blk + NBLK - 1) / NBLK));      // role waves of this block that own a context unit
     const int cb = has_ctx ? g_id / CU_PER_ROW : 0, c8 = has_ctx ? g_id % CU_PER_ROW : 0;
     unsigned mraw[2 * KT];                            // token mask bytes of positions 128 k + 2 lane (+ 1): requested here, looked at behind barrier #1
     float wc_old[2 * KT];
@@ -837,7 +842,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             *reinterpret_cast<f32x4*>(xs + (size_t)(idx / (RNN / 4)) * KX + (idx % (RNN / 4)) * 4) = sv[i];
         }
         for (int i = tid; i < (NBT - B) * ENC; i += NTHR) xs[(size_t)(B + i / ENC) * KX + RNN + i % ENC] = 0.f;
-        if (tid < 8) ctl[tid] = 0;
+        if (tid < 16) ctl[tid] = 0;
     };
 
     if (wave < 4) {
@@ -1000,7 +1005,17 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             if (r == 0 && p == 0) FTR(1, 5);
         }
     }
-    if (r == 3 && lane == 0) stamp(ctl + 3);          // the last of the block's waves to publish its energies (it did the query first)
+    // the stamp of the energies hop: left by the last of the block's waves that published any (with fewer than 1 024 (row,
+    // position) pairs the query wave owns none and used to stamp ~2.5 us before the first energy existed: every context unit
+    // then looked early and kept polling).  A block without a producer estimates: query hop + location term.
+    {
+        const int n_e = min(4, max(0, (B * Tin - blk + NBLK - 1) / NBLK));
+        if (g_id < B * Tin) {
+            if (lane == 0) stamp_last(ctl + 8, n_e, ctl + 3);
+        } else if (n_e == 0 && r == 3 && lane == 0) {
+            stamp(ctl + 3, 200);
+        }
+    }
     if (has_ctx) {                                    // softmax of row cb, 8 context columns
         unsigned ent[KT];
         const unsigned rowe = X.e + (unsigned)cb * X.TinP;
@@ -1069,7 +1084,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             publish(a.xch + X.ctx + o, tag, acc);
             a.ctx[o] = acc;                           // for X(t + 1) / the tail projection (next kernel: plain load)
         }
-        if (r == R_LAST_CTX && lane == 0) stamp(ctl + 4);
+        if (lane == 0) stamp_last(ctl + 9, n_c, ctl + 4);
         if (r == 0) FTR(1, 7);
         if (c8 == 0) {                                // the row's bookkeeping: alignments, history, arg max
             float best = -1.f;
@@ -1097,8 +1112,8 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
                 if (lane == 0) a.mainatt[(par ^ 1) * B + cb] = besti;
             }
         }
-    } else if (r == R_LAST_CTX && lane == 0) {
-        stamp(ctl + 4);                               // (this block's wave r owns no unit: B * enc / 8 is not a multiple of 256)
+    } else if (n_c == 0 && r == 0 && lane == 0) {
+        stamp(ctl + 4, 250);                          // a block without a context unit (fewer than 4 rows): energies hop + softmax from here
     }
     {   // every role wave fetches a quarter of the context of all rows into the LDS rows
         constexpr int NQ = NBT * ENC / 2 / 256;       // pairs per lane
@@ -1148,7 +1163,7 @@ __global__ void fused_advance_kernel(FusedState* st, const int* flags, const int
 
 size_t lds_x(int NBT, int ENC) { return ((size_t)NBT * (2 * RNN + ENC) + (size_t)NBT * PRE + 8) * sizeof(float); }
 size_t lds_y(int NBT, int ENC, int KT) {
-    return ((size_t)NBT * (2 * RNN + ENC) + 2 * LOCK * ATT + 4 * KT * 128 * 9 + 8) * sizeof(float);
+    return ((size_t)NBT * (2 * RNN + ENC) + 2 * LOCK * ATT + 4 * KT * 128 * 9 + 16) * sizeof(float);
 }
 
 template <int NBT, int ENC, bool HW>
@@ -1236,8 +1251,8 @@ int fused_enqueue_chunk(tts_hip_engine* e, hipStream_t st, const FusedCall& c) {
     // next to the (pausing) weight stream.  Found per kernel shape with scripts/fused_sweep.py on the debug build (round 4: the
     // sweep now really changes the delays of the graph it times); a wrong value costs time, never correctness.
     static const int kDelay[2][2][5] = {
-        {{70, 80, 120, 60, 100}, {20, 40, 120, 20, 60}},       // 4-row kernels: fp32 weights, fp16 weights
-        {{30, 90, 150, 60, 60}, {40, 40, 120, 20, 70}}};       // 8-row kernels
+        {{60, 80, 100, 40, 60}, {20, 40, 80, 20, 60}},         // 4-row kernels: fp32 weights, fp16 weights
+        {{30, 90, 150, 40, 60}, {40, 40, 120, 20, 70}}};       // 8-row kernels
     for (int i = 0; i < 5; ++i) a.delay[i] = kDelay[c.B > 4 ? 1 : 0][c.half_w ? 1 : 0][i];
 #ifdef TTS_DEBUG_HOOKS
     if (const char* dl = getenv("TTS_FUSED_DELAYS")) {            // "a,b,c,d,e"
