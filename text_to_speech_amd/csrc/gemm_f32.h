@@ -911,7 +911,6 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
             // buffers are free now, so each wave transposes its tiles one at a time through a private 32 x 36 float patch of
             // LDS: afterwards lane l holds 4 consecutive columns of row (l / 8) + 8 pass, i.e. 16-byte accesses, 8 lanes per
             // 128-byte row segment.  (Residual GEMM of the split-fp16 mode: 0.61 -> see DESIGN.)
-            __builtin_amdgcn_s_barrier();                         // every wave is done reading the last tile
             float* patch = smem + wave * (32 * 36);
             const int prow = lane >> 3, pc4 = (lane & 7) * 4;
             bool accum = second ? g.acc1 : g.acc0;
@@ -923,6 +922,25 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
 #else
             constexpr bool kNoMaster = false, kPairMaster = false;
 #endif
+            // read-modify-write: in the HBM-bound fp16 residual launch the old values of ALL this wave's tiles are requested up
+            // front (tile by tile they are RT x CT dependent HBM latencies per block): 290 -> 263 - 273 us.  Not in the fp32 and
+            // split-fp16 kernels, which are MFMA-bound and lose 1.5 % / gain nothing with 64 more live registers in the epilogue.
+#ifndef TTS_EPI_PREFETCH
+#define TTS_EPI_PREFETCH 1
+#endif
+            constexpr bool kPrefetch = TTS_EPI_PREFETCH && HALF && PL == 1 && RT * CT <= 4;
+            f32x4 oldall[kPrefetch ? RT * CT : 1][4];
+            if (kPrefetch && accum) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            oldall[kPrefetch ? i * CT + j : 0][q] = *reinterpret_cast<const f32x4*>(
+                                outp + (long long)(m0 + wr * RT * 32 + i * 32 + prow + 8 * q) * ldo + ncol0 + j * 32 + pc4);
+            }
+            __builtin_amdgcn_s_barrier();                         // every wave is done reading the last tile
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -933,7 +951,8 @@ __global__ __launch_bounds__(WR * WC * 64, OCC) void gemm_f32_kernel(const GemmA
                     if (accum) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            oldv[q] = *reinterpret_cast<const f32x4*>(outp + (long long)(mrow0 + prow + 8 * q) * ldo + ncol);
+                            oldv[q] = kPrefetch ? oldall[kPrefetch ? i * CT + j : 0][q]
+                                                : *reinterpret_cast<const f32x4*>(outp + (long long)(mrow0 + prow + 8 * q) * ldo + ncol);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) patch[trow(r) * 36 + tcol(r)] = A(i, j, r);
