@@ -208,6 +208,24 @@ def test_long_inputs_cover_every_attention_path(gpu_engine, taco_weights, taco_c
     assert np.all(out.attention_weights[1, :, lens[1]:] == 0)
 
 
+@pytest.mark.parametrize('B,Tin', [(5, 45), (7, 150), (6, 128)])
+def test_partially_filled_row_tiles(gpu_engine, taco_weights, taco_cfg, B, Tin):
+    """Batch 5 - 7 runs the 8-row kernels of the fused step with empty rows: fewer (row, position) pairs than role waves and
+    fewer context units than slots, so some waves of a block publish nothing (the hop stamps are then left by the block's last
+    real publisher, csrc/taco_fused.hip `stamp_last`); 150 tokens add the two-positions-per-wave template."""
+    from oracle import tacotron2_ref
+    lens = [Tin, Tin - 7, max(3, Tin // 3), Tin - 1, max(2, Tin // 2), Tin - 20, 5][:B]
+    tok = _tokens(B, Tin, lens, seed=B * 1000 + Tin)
+    masks = (np.random.default_rng(B).random((B, 14, 2, 256)) >= 0.5).astype(np.float32) * 2.0
+    ref = tacotron2_ref.infer(tok, taco_weights, taco_cfg, max_length=14, early_stopping=False, prenet_masks=masks)
+    out = gpu_engine.tacotron2_infer(tok, max_len=14, early_stopping=False, prenet_masks=masks)
+    if MODE == 'fused':
+        assert gpu_engine.last_decoder_mode == 'fused'
+    _check(out, ref)
+    for b in range(B):
+        assert np.all(out.attention_weights[b, :, lens[b]:] == 0)
+
+
 def test_padding_and_batch_composition_do_not_change_a_row(gpu_engine):
     """Properties the reference's masking guarantees, independent of any oracle (location_sensitive_attention.py:96-102,
     tacotron2_arch.py:625-627): a sentence gives the same frames whether its token row is padded to 40 or to 120 positions,
