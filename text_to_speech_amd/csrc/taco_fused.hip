@@ -401,10 +401,12 @@ __device__ __forceinline__ EntryState look_entry(EntryLoads l) {
     return e;
 }
 
-// Quiet windows (TTS_FUSED_QUIET, experiment of round 4): a hop's price sits in the consumer's memory queue and on a fabric that
-// the weight stream keeps busy.  A role wave raises an LDS counter from the moment its producer has published until its own poll
-// has succeeded; the LSTM waves do not request new weight slices while the counter is up (the 256 blocks run in lock step, so the
-// whole chip's stream pauses around every hop).  Bounded wait: the stream resumes on its own after ~0.1 ms.
+// Quiet windows (round 4): a hop's price sits in the consumer's memory queue and on a fabric that the weight stream
+// keeps busy.  A role wave raises an LDS counter shortly before its timed first look at a hop (TTS_FUSED_QUIET_LEAD ticks before)
+// and lowers it when its poll has succeeded; the LSTM waves do not request new weight slices while the counter is up (the 256
+// blocks run in lock step, so the whole chip's stream pauses around every hop).  Measured per hop: the hops of kernel Y and the
+// p1 hop of kernel X pay, the p2 hop does not (bits of TTS_FUSED_QUIET).  Bounded wait: the stream resumes on its own after
+// 2 048 looks (~0.1 ms); the tags decide correctness, the counter only delays requests.
 #ifndef TTS_FUSED_QUIET
 #define TTS_FUSED_QUIET 3          // bit 0: the p1 hop of kernel X, bit 2: its p2 hop, bit 1: the hops of kernel Y
 #endif
