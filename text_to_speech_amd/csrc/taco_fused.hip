@@ -9,7 +9,7 @@
 // paying at 4 rows: its all-to-all hops carry B x 1024 tagged values to every CU.  Here:
 //
 //   * the two all-to-all edges of a step (h_dec -> everyone, h_att -> everyone: B x 1024 values each) are KERNEL BOUNDARIES
-//     (1.5 us each, plain loads afterwards); the light edges (p1, p2, finished count, q, energies: <= B x 256 values) and the
+//     (3.5 - 4.2 us from the last wave of one kernel to the landed first loads of the next, plain loads afterwards); the light edges (p1, p2, finished count, q, energies: <= B x 256 values) and the
 //     context (B x enc values) are tagged 8-byte (step, value) exchanges INSIDE a kernel, as in taco_persist.hip;
 //   * every block is 8 waves: 4 LSTM waves (unit u = 4 blk + w) that stream their 4 gate rows through a small register
 //     window (PF slices of 256 columns in flight, consumed as they arrive; the slices that wait for the chain are requested
@@ -29,6 +29,11 @@
 // X(t) did.  A chunk = 32 steps + a tail projection (the frame of the chunk's last step) is one hipGraph.
 // Every wait is bounded; a timeout raises flags[0], later kernels return at once and the host re-runs the call on the
 // 7-kernel graph.
+//
+// Round 4: the weight stream pauses around the hops (quiet windows, below); everything a kernel's entry needs --
+// loop state, abort flag, staging rows, the role waves' operands -- is requested before the first wait; a hop's time stamp is
+// left by the block's LAST publisher (`stamp_last`), so partially filled shapes (batch 5 - 7, fewer than 1 024 (row, position)
+// pairs) do not look early; first-look delays per kernel shape (`kDelay`, scripts/fused_sweep.py).
 #include "taco_fused.h"
 
 #include <cstdio>
