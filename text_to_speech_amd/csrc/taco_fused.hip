@@ -26,7 +26,7 @@
 //
 // Loop control lives on the device (FusedState): X(t) runs if step t - 1 ran; it computes the stop tokens of step t - 1,
 // publishes the finished count with p2, and every block decides "all rows have fired" from that one value; Y(t) runs if
-// X(t) did.  A chunk = 32 steps + a tail projection (the frame of the chunk's last step) is one hipGraph.
+// X(t) did.  A chunk = FUSED_CHUNK (64) steps + a tail projection (the frame of the chunk's last step) is one hipGraph.
 // Every wait is bounded; a timeout raises flags[0], later kernels return at once and the host re-runs the call on the
 // 7-kernel graph.
 //
