@@ -729,6 +729,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     constexpr int MPF = 16 * KT;                      // positions per lane of a context unit (8 time slices x 8 columns per wave)
     constexpr int CU_PER_ROW = ENC / 8;
     constexpr int NL4 = 2 * LOCK * ATT / 4, NSL = (NL4 + 255) / 256;             // location map: float4 per role thread
+    constexpr int NSL3 = (NL4 + 191) / 192;                                       // ... per thread of three role waves (two_pairs)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                                  // [NBT][KX]
     float* wl = xs + NBT * KX;                        // [62][128]
@@ -809,6 +810,10 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
     }
     const bool has_ctx = role && g_id < B * CU_PER_ROW;
     const int n_c = min(4, max(0, (B * CU_PER_ROW - blk + NBLK - 1) / NBLK));      // role waves of this block that own a context unit
+    // some role wave owns two (row, position) pairs (8 rows of more than 128 tokens): the batched energies path below.  With fp16
+    // LSTM weights only: there it takes 27.4 -> 26.1 us per step at 256 tokens; with fp32 weights (a longer stream under the
+    // hops) it measured +0.3 us, and shapes without a second pair lose 0.3 - 1.0 us to the three-wave staging of the map.
+    const bool two_pairs = NPOS > 1 && HW && B * Tin > 4 * NBLK;
     const int cb = has_ctx ? g_id / CU_PER_ROW : 0, c8 = has_ctx ? g_id % CU_PER_ROW : 0;
     unsigned mraw[2 * KT];                            // token mask bytes of positions 128 k + 2 lane (+ 1): requested here, looked at behind barrier #1
     float wc_old[2 * KT];
@@ -922,6 +927,35 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
         asm volatile("" : "+v"(mraw[i]));
         if (mraw[i]) on_bits |= 1u << i;
     }
+    if (two_pairs) {
+        // two (row, position) pairs per wave (8 rows of more than 128 tokens): the location terms are on the chain, so the map
+        // is staged by the three role waves that do not compute the query (the query wave stores its share only behind its
+        // publish, ~0.9 us later) and the terms start as soon as those three have met on the LDS counter
+        if (!is_q) {
+            const int rt = r * 64 + lane;             // 0 .. 191
+            f32x4 lv[NSL3];
+#pragma unroll
+            for (int i = 0; i < NSL3; ++i) {
+                const int idx = rt + i * 192;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                lv[i] = idx < NL4 ? *reinterpret_cast<const f32x4*>(a.wloc + (size_t)idx * 4) : zero;
+            }
+#pragma unroll
+            for (int i = 0; i < NSL3; ++i) {
+                const int idx = rt + i * 192;
+                if (idx < NL4) *reinterpret_cast<f32x4*>(wl + (size_t)idx * 4) = lv[i];
+            }
+            if (lane == 0) __hip_atomic_fetch_add(ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            float sm[HB];
+            const int qcol[4] = {0, 256, 512, 768};
+            role_dots<HB, 4>(sm, RQ, xs + (size_t)qrow * KX, KX, qcol, lane);
+            FTR(1, 15);
+            if (lane < HB && qrow + lane < B) publish(a.xch + X.q + (qrow + lane) * ATT + qdim, tag, pick_row<HB>(sm, lane));
+            if (lane == 0) stamp(ctl + 2);
+            FTR(1, 3);
+        }
+    } else
     {   // the location map (31 KiB, only the energies need it): fetched by the role waves now, while the query is computed
         // and published, instead of sitting in front of barrier #1; the four waves meet on an LDS counter
         const int rt = tid - 256;
@@ -968,14 +1002,63 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
                                                      (unsigned)tt * (ENC * 4u) + (lane & 1) * 16u, 0, 0, 0);
         }
     }
-    {   // all four parts of the location map are in LDS
+    {   // all parts of the location map are in LDS
         long long spins = 0;
-        while (lds_peek(ctl + 5) < 4) {
+        while (lds_peek(ctl + 5) < (two_pairs ? 3 : 4)) {
             if (++spins > LDS_SPIN_LIMIT) { P.give_up(); break; }
             if ((spins & 255) == 0 && lds_peek(ctl)) break;
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    if (two_pairs) {
+        // the location terms of BOTH positions first, then ONE look at the query rows they need (term, look, term, look put a
+        // second round trip on the chain -- and such a wave may be a context unit, whose slice every block then waits for)
+        f32x2 loc[NPOS];
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p) {
+            loc[p] = pmv[p];
+            if (g_id + 1024 * p < B * Tin) {          // wave-uniform
+#pragma unroll
+                for (int i = 0; i < LOCK; ++i) {
+                    const float sp = lane_bcast(cp[p], i), sc = lane_bcast(cc[p], i);
+                    const f32x2 w0 = *reinterpret_cast<const f32x2*>(wl + (2 * i) * ATT + lane * 2);
+                    const f32x2 w1 = *reinterpret_cast<const f32x2*>(wl + (2 * i + 1) * ATT + lane * 2);
+                    loc[p][0] = fmaf(sp, w0[0], loc[p][0]);
+                    loc[p][1] = fmaf(sp, w0[1], loc[p][1]);
+                    loc[p][0] = fmaf(sc, w1[0], loc[p][0]);
+                    loc[p][1] = fmaf(sc, w1[1], loc[p][1]);
+                }
+            }
+        }
+        if (g_id < B * Tin) {                         // this wave owns at least one position
+            wait_stamp(P, ctl + 2, quiet_pre(a.delay[2]));
+            quiet_begin<1>(ctl, lane);
+            wait_stamp(P, ctl + 2, a.delay[2]);
+            unsigned ent[NPOS];
+#pragma unroll
+            for (int p = 0; p < NPOS; ++p) {
+                const int idx = g_id + 1024 * p < B * Tin ? g_id + 1024 * p : g_id;
+                ent[p] = X.q + (unsigned)(idx / Tin) * ATT + (unsigned)lane * 2;
+            }
+            f32x2 qv[NPOS];
+            poll_pairs<NPOS>(P, ent, tag, qv);
+            quiet_end<1>(ctl, lane);
+            if (r == 0) FTR(1, 4);
+#pragma unroll
+            for (int p = 0; p < NPOS; ++p) {
+                const int idx = g_id + 1024 * p;
+                if (idx < B * Tin) {
+                    const int b = idx / Tin, tau = idx - b * Tin;
+                    float e = vv[0] * tanh_fast(qv[p][0] + loc[p][0]);
+                    e = fmaf(vv[1], tanh_fast(qv[p][1] + loc[p][1]), e);
+                    e = wave_sum(e);
+                    if (lane == 0) publish(a.xch + X.e + (unsigned)b * X.TinP + tau, tag, e);
+                    if (lane == 1 && tau == Tin - 1 && (Tin & 1)) publish(a.xch + X.e + (unsigned)b * X.TinP + tau + 1, tag, 0.f);
+                }
+            }
+            if (r == 0) FTR(1, 5);
+        }
+    } else {
     // energies of the positions this wave owns: the location term first (it only needs the previous alignments)
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
@@ -1011,6 +1094,7 @@ __global__ __launch_bounds__(NTHR) void fused_y_kernel(const FusedArgs a, const 
             if (lane == 1 && tau == Tin - 1 && (Tin & 1)) publish(a.xch + X.e + (unsigned)b * X.TinP + tau + 1, tag, 0.f);
             if (r == 0 && p == 0) FTR(1, 5);
         }
+    }
     }
     // the stamp of the energies hop: left by the last of the block's waves that published any (with fewer than 1 024 (row,
     // position) pairs the query wave owns none and used to stamp ~2.5 us before the first energy existed: every context unit
