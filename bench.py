@@ -265,10 +265,12 @@ def secondary_metrics(eng, dev, rank):
                 reps = 3
                 times = {}
                 for n_steps in (FRAMES // 2, FRAMES):
-                    t0 = time.perf_counter()
+                    runs = []
                     for _ in range(reps):
+                        t0 = time.perf_counter()
                         eng.tacotron2_infer(tok_d, max_len=n_steps, early_stopping=False, want_attention=False, precision=prec)
-                    times[n_steps] = (time.perf_counter() - t0) / reps
+                        runs.append(time.perf_counter() - t0)
+                    times[n_steps] = sorted(runs)[reps // 2]     # median of three: one disturbed call does not move the figure
                 dt = times[FRAMES]
                 step_us = 1e6 * (times[FRAMES] - times[FRAMES // 2]) / (FRAMES - FRAMES // 2)
                 out[f'{key}_mel_frames_per_s'] = B * FRAMES / dt
