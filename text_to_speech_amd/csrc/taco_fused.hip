@@ -361,6 +361,9 @@ __device__ __forceinline__ void wait_stamp(const WavePoll& P, const lds_int* ts,
     }
     while ((int)((unsigned)wall_clock64() - (unsigned)(v + delay)) < 0) __builtin_amdgcn_s_sleep(1);
 }
+#ifndef TTS_POLL_SLEEP
+#define TTS_POLL_SLEEP 4              // 64-cycle units between two looks of a poll that missed
+#endif
 template <int N>
 __device__ __forceinline__ void poll_pairs(const WavePoll& P, const unsigned (&entry)[N], unsigned tag, f32x2 (&out)[N]) {
     u32x4 v[N];
@@ -376,7 +379,7 @@ __device__ __forceinline__ void poll_pairs(const WavePoll& P, const unsigned (&e
         ++spins;
         if (spins > SPIN_LIMIT) { P.give_up(); break; }
         if (P.should_stop(spins)) break;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(TTS_POLL_SLEEP);
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = f32x2{bitsf(v[i][0]), bitsf(v[i][2])};
